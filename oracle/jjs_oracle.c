@@ -1,0 +1,612 @@
+/*
+ * CPU oracle (plain C) for Schnorr-on-JubJub verification -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline ("kind": "port").  The
+ * product path (jubjub_schnorr_amd/, libjjs_gpu.so) never links or calls it.
+ *
+ * It restates, with the reference's own algorithm (4x64-bit Montgomery limbs, bit-serial
+ * double-and-add over 252 bits with an unconditional niels addition per bit, a full
+ * [r]P subgroup check on every point, un-optimised Hades rounds):
+ *   PublicKey::verify          /root/reference/src/keys/public.rs:114-135, is_valid :159-164
+ *   Signature::is_valid        src/signatures.rs:93-98 ; challenge_hash :122-140
+ *   PublicKeyDouble::verify    src/keys/public/double.rs:86-117, is_valid :145-157
+ *   SignatureDouble::is_valid  src/signatures/double.rs:108-119 ; challenge_hash :151-177
+ *   PublicKeyVarGen::verify    src/keys/public/var_gen.rs:107-133, is_valid :160-172
+ *   challenge_hash (var-gen)   src/signatures/var_gen.rs:121-142
+ *   sign / sign_double / sign  src/keys/secret.rs:174-194, src/keys/secret/double.rs:56-85,
+ *                              src/keys/secret/var_gen.rs:228-256, src/nonce.rs:26-107
+ * The field/curve/hash arithmetic is in crates absent from /root/reference
+ * (dusk-bls12_381 0.14, dusk-jubjub 0.15, dusk-poseidon 0.42.0-rc.0 + dusk-safe); their
+ * algorithms are restated per SURVEY.md Appendix A.  Parity is PINNED: tests/test_oracle_c.py
+ * checks this file against the reference's KAT vectors (tests/golden/reference_kat.json) and
+ * against oracle/jjs_oracle.py on random inputs.
+ *
+ * Status codes: 0 Ok, 1 InvalidPoint, 2 InvalidSignature (src/error.rs:17-19, precedence
+ * src/keys/public.rs:119-132), 3 Malformed (non-canonical encoding).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "jjs_oracle_constants.h"
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+
+/* ------------------------------------------------------------------ generic 256-bit helpers */
+static inline int ge256(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; --i) {
+        if (a[i] > b[i]) return 1;
+        if (a[i] < b[i]) return 0;
+    }
+    return 1;
+}
+static inline uint64_t sub256(uint64_t out[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        out[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+    return borrow;
+}
+static inline uint64_t add256(uint64_t out[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t carry = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 s = (u128)a[i] + b[i] + carry;
+        out[i] = (uint64_t)s;
+        carry = (uint64_t)(s >> 64);
+    }
+    return carry;
+}
+static inline void load_le(uint64_t out[4], const uint8_t *b) { memcpy(out, b, 32); }
+static inline void store_le(uint8_t *b, const uint64_t in[4]) { memcpy(b, in, 32); }
+
+/* Montgomery product, CIOS, modulus p (< 2^255 or 2^252), inv = -p^-1 mod 2^64 */
+static inline void mont_mul(uint64_t out[4], const uint64_t a[4], const uint64_t b[4],
+                            const uint64_t p[4], uint64_t inv) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; ++j) {
+            u128 cur = (u128)a[j] * b[i] + t[j] + carry;
+            t[j] = (uint64_t)cur;
+            carry = (uint64_t)(cur >> 64);
+        }
+        u128 cur = (u128)t[4] + carry;
+        t[4] = (uint64_t)cur;
+        t[5] = (uint64_t)(cur >> 64);
+        uint64_t m = t[0] * inv;
+        cur = (u128)m * p[0] + t[0];
+        carry = (uint64_t)(cur >> 64);
+        for (int j = 1; j < 4; ++j) {
+            cur = (u128)m * p[j] + t[j] + carry;
+            t[j - 1] = (uint64_t)cur;
+            carry = (uint64_t)(cur >> 64);
+        }
+        cur = (u128)t[4] + carry;
+        t[3] = (uint64_t)cur;
+        t[4] = t[5] + (uint64_t)(cur >> 64);
+    }
+    if (t[4] || ge256(t, p)) sub256(out, t, p); else memcpy(out, t, 32);
+}
+
+/* ------------------------------------------------------------------ Fq */
+static inline void fq_mul(fe *o, const fe *a, const fe *b) { mont_mul(o->l, a->l, b->l, JJO_Q, JJO_Q_INV); }
+static inline void fq_sqr(fe *o, const fe *a) { mont_mul(o->l, a->l, a->l, JJO_Q, JJO_Q_INV); }
+static inline void fq_add(fe *o, const fe *a, const fe *b) {
+    uint64_t t[4];
+    add256(t, a->l, b->l);             /* < 2^256 since both < q < 2^255 */
+    if (ge256(t, JJO_Q)) sub256(o->l, t, JJO_Q); else memcpy(o->l, t, 32);
+}
+static inline void fq_sub(fe *o, const fe *a, const fe *b) {
+    uint64_t t[4];
+    if (sub256(t, a->l, b->l)) add256(t, t, JJO_Q);
+    memcpy(o->l, t, 32);
+}
+static inline void fq_dbl(fe *o, const fe *a) { fq_add(o, a, a); }
+static inline int fq_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fq_eq(const fe *a, const fe *b) { return memcmp(a->l, b->l, 32) == 0; }
+static inline void fq_one(fe *o) { memcpy(o->l, JJO_Q_ONE, 32); }
+static inline void fq_zero(fe *o) { memset(o->l, 0, 32); }
+/* canonical LE bytes -> Montgomery; returns 0 if >= q */
+static inline int fq_from_bytes(fe *o, const uint8_t *b) {
+    uint64_t t[4];
+    load_le(t, b);
+    if (ge256(t, JJO_Q)) return 0;
+    mont_mul(o->l, t, JJO_Q_R2, JJO_Q, JJO_Q_INV);
+    return 1;
+}
+static inline void fq_to_canon(uint64_t out[4], const fe *a) {
+    static const uint64_t one[4] = {1, 0, 0, 0};
+    mont_mul(out, a->l, one, JJO_Q, JJO_Q_INV);
+}
+static inline void fq_to_bytes(uint8_t *b, const fe *a) {
+    uint64_t t[4];
+    fq_to_canon(t, a);
+    store_le(b, t);
+}
+static void fq_inv(fe *o, const fe *a) { /* a^(q-2), square-and-multiply */
+    uint64_t e[4];
+    static const uint64_t two[4] = {2, 0, 0, 0};
+    sub256(e, JJO_Q, two);
+    fe acc;
+    fq_one(&acc);
+    for (int i = 254; i >= 0; --i) {
+        fq_sqr(&acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, a);
+    }
+    *o = acc;
+}
+
+/* ------------------------------------------------------------------ Fr (only for signing) */
+static inline void fr_mul_canon(uint64_t o[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t am[4], t[4];
+    mont_mul(am, a, JJO_R_R2, JJO_R, JJO_R_INV);   /* a*R */
+    mont_mul(t, am, b, JJO_R, JJO_R_INV);          /* a*b */
+    memcpy(o, t, 32);
+}
+static inline void fr_sub_canon(uint64_t o[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t t[4];
+    if (sub256(t, a, b)) add256(t, t, JJO_R);
+    memcpy(o, t, 32);
+}
+
+/* ------------------------------------------------------------------ JubJub, extended coords */
+typedef struct { fe u, v, z, t; } ext_t;            /* t = u*v/z */
+typedef struct { fe vpu, vmu, z, t2d; } niels_t;    /* v+u, v-u, z, 2d*t */
+
+static const fe *D2(void) { return (const fe *)JJO_D2_M; }
+static const fe *DD(void) { return (const fe *)JJO_D_M; }
+
+static void ext_identity(ext_t *p) { fq_zero(&p->u); fq_one(&p->v); fq_one(&p->z); fq_zero(&p->t); }
+static void ext_from_affine(ext_t *p, const fe *u, const fe *v) {
+    p->u = *u; p->v = *v; fq_one(&p->z); fq_mul(&p->t, u, v);
+}
+static void niels_from_ext(niels_t *n, const ext_t *p) {
+    fq_add(&n->vpu, &p->v, &p->u);
+    fq_sub(&n->vmu, &p->v, &p->u);
+    n->z = p->z;
+    fq_mul(&n->t2d, &p->t, D2());
+}
+static void niels_identity(niels_t *n) { fq_one(&n->vpu); fq_one(&n->vmu); fq_one(&n->z); fq_zero(&n->t2d); }
+/* dedicated doubling: 4S + 4M */
+static void ext_double(ext_t *o, const ext_t *p) {
+    fe uu, vv, zz2, uv2, vpu, vmu, tmp, t, z;
+    fq_sqr(&uu, &p->u);
+    fq_sqr(&vv, &p->v);
+    fq_sqr(&tmp, &p->z); fq_dbl(&zz2, &tmp);
+    fq_add(&tmp, &p->u, &p->v); fq_sqr(&uv2, &tmp);
+    fq_add(&vpu, &vv, &uu);                 /* v^2 + u^2 */
+    fq_sub(&vmu, &vv, &uu);                 /* v^2 - u^2 */
+    fq_sub(&t, &uv2, &vpu);                 /* 2uv */
+    fq_sub(&z, &zz2, &vmu);                 /* 2z^2 - (v^2 - u^2) */
+    /* completed point (U=t, V=vpu, Z=vmu, T=z) -> extended */
+    fq_mul(&o->u, &t, &z);
+    fq_mul(&o->v, &vpu, &vmu);
+    fq_mul(&o->z, &vmu, &z);
+    fq_mul(&o->t, &t, &vpu);
+}
+/* extended + niels: 8M */
+static void ext_add_niels(ext_t *o, const ext_t *p, const niels_t *n) {
+    fe a, b, c, d, t0, t1;
+    fq_sub(&t0, &p->v, &p->u); fq_mul(&a, &t0, &n->vmu);
+    fq_add(&t0, &p->v, &p->u); fq_mul(&b, &t0, &n->vpu);
+    fq_mul(&c, &p->t, &n->t2d);
+    fq_mul(&t1, &p->z, &n->z); fq_dbl(&d, &t1);
+    fe e, f, g, h;
+    fq_sub(&e, &b, &a); fq_sub(&f, &d, &c); fq_add(&g, &d, &c); fq_add(&h, &b, &a);
+    fq_mul(&o->u, &e, &f);
+    fq_mul(&o->v, &g, &h);
+    fq_mul(&o->z, &f, &g);
+    fq_mul(&o->t, &e, &h);
+}
+static void ext_add(ext_t *o, const ext_t *p, const ext_t *q) {
+    niels_t n;
+    niels_from_ext(&n, q);
+    ext_add_niels(o, p, &n);
+}
+/* [k]P, k = 32 LE bytes; MSB-first over the low 252 bits, unconditional add per bit */
+static void ext_mul(ext_t *o, const ext_t *p, const uint8_t k[32]) {
+    niels_t base, zero;
+    niels_from_ext(&base, p);
+    niels_identity(&zero);
+    ext_t acc;
+    ext_identity(&acc);
+    for (int i = 251; i >= 0; --i) {
+        ext_double(&acc, &acc);
+        int bit = (k[i >> 3] >> (i & 7)) & 1;
+        ext_add_niels(&acc, &acc, bit ? &base : &zero);
+    }
+    *o = acc;
+}
+static int ext_is_identity(const ext_t *p) { return fq_is_zero(&p->u) && fq_eq(&p->v, &p->z); }
+static int affine_on_curve(const fe *u, const fe *v) {
+    fe u2, v2, lhs, rhs, one;
+    fq_sqr(&u2, u); fq_sqr(&v2, v);
+    fq_sub(&lhs, &v2, &u2);
+    fq_mul(&rhs, &u2, &v2); fq_mul(&rhs, &rhs, DD());
+    fq_one(&one); fq_add(&rhs, &rhs, &one);
+    return fq_eq(&lhs, &rhs);
+}
+static void ext_to_affine(fe *u, fe *v, const ext_t *p) {
+    fe zi;
+    fq_inv(&zi, &p->z);
+    fq_mul(u, &p->u, &zi);
+    fq_mul(v, &p->v, &zi);
+}
+static uint8_t R_BYTES[32];
+static int r_bytes_init = 0;
+static void init_r_bytes(void) { if (!r_bytes_init) { store_le(R_BYTES, JJO_R); r_bytes_init = 1; } }
+
+/* is_torsion_free && is_on_curve && !is_identity */
+static int point_valid(const ext_t *p) {
+    ext_t rp;
+    ext_mul(&rp, p, R_BYTES);
+    int tf = ext_is_identity(&rp);
+    int oc = affine_on_curve(&p->u, &p->v);     /* z == 1 at the boundary */
+    int id = ext_is_identity(p);
+    return tf && oc && !id;
+}
+
+/* ------------------------------------------------------------------ Hades / SAFE sponge */
+static void hades_permute(fe s[5]) {
+    for (int rnd = 0; rnd < 68; ++rnd) {
+        for (int i = 0; i < 5; ++i) fq_add(&s[i], &s[i], (const fe *)JJO_RC_M[5 * rnd + i]);
+        int full = (rnd < 4) || (rnd >= 64);
+        for (int i = full ? 0 : 4; i < 5; ++i) {
+            fe x2, x4;
+            fq_sqr(&x2, &s[i]); fq_sqr(&x4, &x2); fq_mul(&s[i], &x4, &s[i]);
+        }
+        fe n[5];
+        for (int i = 0; i < 5; ++i) {
+            fe acc, t;
+            fq_mul(&acc, (const fe *)JJO_MDS_M[i][0], &s[0]);
+            for (int j = 1; j < 5; ++j) { fq_mul(&t, (const fe *)JJO_MDS_M[i][j], &s[j]); fq_add(&acc, &acc, &t); }
+            n[i] = acc;
+        }
+        memcpy(s, n, sizeof(n));
+    }
+}
+/* Hash::digest(Domain::Other, in[0..k))[0], Montgomery in/out */
+static void poseidon_digest(fe *out, const fe *in, size_t k) {
+    fe s[5];
+    s[0] = *(const fe *)JJO_SPONGE_TAG_M[k];
+    for (int i = 1; i < 5; ++i) fq_zero(&s[i]);
+    int pos = 0;
+    for (size_t i = 0; i < k; ++i) {
+        if (pos == 4) { hades_permute(s); pos = 0; }
+        fq_add(&s[1 + pos], &s[1 + pos], &in[i]);
+        ++pos;
+    }
+    hades_permute(s);
+    *out = s[1];
+}
+static void truncate250(uint8_t c[32], const fe *h) {
+    fq_to_bytes(c, h);
+    c[31] &= 0x03;
+}
+
+/* ------------------------------------------------------------------ verify */
+static int load_point(ext_t *p, const uint8_t *b) {
+    fe u, v;
+    if (!fq_from_bytes(&u, b) || !fq_from_bytes(&v, b + 32)) return 0;
+    ext_from_affine(p, &u, &v);
+    return 1;
+}
+static int scalar_canonical(const uint8_t *b) {
+    uint64_t t[4];
+    load_le(t, b);
+    return !ge256(t, JJO_R);
+}
+/* to_hash_inputs(): the reference normalises with one inversion per point */
+static void hash_inputs(fe out[2], const ext_t *p) { ext_to_affine(&out[0], &out[1], p); }
+
+/* u*base + c*pk == r  (projective equality) */
+static int equation(const ext_t *base, const uint8_t u[32], const ext_t *pk, const uint8_t c[32], const ext_t *r) {
+    ext_t a, b, s;
+    ext_mul(&a, base, u);
+    ext_mul(&b, pk, c);
+    ext_add(&s, &a, &b);
+    fe l, rr;
+    fq_mul(&l, &s.u, &r->z); fq_mul(&rr, &r->u, &s.z);
+    if (!fq_eq(&l, &rr)) return 0;
+    fq_mul(&l, &s.v, &r->z); fq_mul(&rr, &r->v, &s.z);
+    return fq_eq(&l, &rr);
+}
+static void gen_points(ext_t *g, ext_t *gn) {
+    ext_from_affine(g, (const fe *)JJO_G_U_M, (const fe *)JJO_G_V_M);
+    ext_from_affine(gn, (const fe *)JJO_GN_U_M, (const fe *)JJO_GN_V_M);
+}
+
+static uint8_t verify_single_one(const uint8_t *u, const uint8_t *R, const uint8_t *PK, const uint8_t *m, uint8_t *c_out) {
+    ext_t r, pk, g, gn;
+    fe mm;
+    if (c_out) memset(c_out, 0, 32);
+    if (!load_point(&r, R) || !load_point(&pk, PK) || !fq_from_bytes(&mm, m) || !scalar_canonical(u)) return 3;
+    fe in[5], t[2];
+    hash_inputs(t, &r); in[0] = t[0]; in[1] = t[1];
+    hash_inputs(t, &pk); in[2] = t[0]; in[3] = t[1];
+    in[4] = mm;
+    fe h; uint8_t c[32];
+    poseidon_digest(&h, in, 5);
+    truncate250(c, &h);
+    if (c_out) memcpy(c_out, c, 32);
+    if (!point_valid(&pk) || !point_valid(&r)) return 1;
+    gen_points(&g, &gn);
+    return equation(&g, u, &pk, c, &r) ? 0 : 2;
+}
+static uint8_t verify_double_one(const uint8_t *u, const uint8_t *R, const uint8_t *Rp, const uint8_t *PK,
+                                 const uint8_t *PKp, const uint8_t *m, uint8_t *c_out) {
+    ext_t r, rp, pk, pkp, g, gn;
+    fe mm;
+    if (c_out) memset(c_out, 0, 32);
+    if (!load_point(&r, R) || !load_point(&rp, Rp) || !load_point(&pk, PK) || !load_point(&pkp, PKp) ||
+        !fq_from_bytes(&mm, m) || !scalar_canonical(u)) return 3;
+    fe in[10], t[2];
+    in[0] = *(const fe *)JJO_DOUBLE_TAG_M;
+    hash_inputs(t, &r); in[1] = t[0]; in[2] = t[1];
+    hash_inputs(t, &rp); in[3] = t[0]; in[4] = t[1];
+    hash_inputs(t, &pk); in[5] = t[0]; in[6] = t[1];
+    hash_inputs(t, &pkp); in[7] = t[0]; in[8] = t[1];
+    in[9] = mm;
+    fe h; uint8_t c[32];
+    poseidon_digest(&h, in, 10);
+    truncate250(c, &h);
+    if (c_out) memcpy(c_out, c, 32);
+    int pk_ok = point_valid(&pk) & point_valid(&pkp);
+    int sig_ok = point_valid(&r) & point_valid(&rp);
+    if (!pk_ok || !sig_ok) return 1;
+    gen_points(&g, &gn);
+    int e1 = equation(&g, u, &pk, c, &r);
+    int e2 = equation(&gn, u, &pkp, c, &rp);
+    return (e1 && e2) ? 0 : 2;
+}
+static uint8_t verify_vargen_one(const uint8_t *u, const uint8_t *R, const uint8_t *PK, const uint8_t *Gen,
+                                 const uint8_t *m, uint8_t *c_out) {
+    ext_t r, pk, gen;
+    fe mm;
+    if (c_out) memset(c_out, 0, 32);
+    if (!load_point(&r, R) || !load_point(&pk, PK) || !load_point(&gen, Gen) || !fq_from_bytes(&mm, m) ||
+        !scalar_canonical(u)) return 3;
+    fe in[7], t[2];
+    hash_inputs(t, &r); in[0] = t[0]; in[1] = t[1];
+    hash_inputs(t, &pk); in[2] = t[0]; in[3] = t[1];
+    hash_inputs(t, &gen); in[4] = t[0]; in[5] = t[1];
+    in[6] = mm;
+    fe h; uint8_t c[32];
+    poseidon_digest(&h, in, 7);
+    truncate250(c, &h);
+    if (c_out) memcpy(c_out, c, 32);
+    int pk_ok = point_valid(&pk) & point_valid(&gen);
+    if (!pk_ok || !point_valid(&r)) return 1;
+    return equation(&gen, u, &pk, c, &r) ? 0 : 2;
+}
+
+static int pick_threads(int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    return threads;
+#else
+    (void)threads;
+    return 1;
+#endif
+}
+
+int jjo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int jjo_verify_single(const uint8_t *u, const uint8_t *R, const uint8_t *PK, const uint8_t *m, size_t n,
+                      uint8_t *status, uint8_t *c_out, int threads) {
+    init_r_bytes();
+    int nt = pick_threads(threads); (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i)
+        status[i] = verify_single_one(u + 32 * i, R + 64 * i, PK + 64 * i, m + 32 * i, c_out ? c_out + 32 * i : 0);
+    return 0;
+}
+int jjo_verify_double(const uint8_t *u, const uint8_t *R, const uint8_t *Rp, const uint8_t *PK, const uint8_t *PKp,
+                      const uint8_t *m, size_t n, uint8_t *status, uint8_t *c_out, int threads) {
+    init_r_bytes();
+    int nt = pick_threads(threads); (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i)
+        status[i] = verify_double_one(u + 32 * i, R + 64 * i, Rp + 64 * i, PK + 64 * i, PKp + 64 * i, m + 32 * i,
+                                      c_out ? c_out + 32 * i : 0);
+    return 0;
+}
+int jjo_verify_vargen(const uint8_t *u, const uint8_t *R, const uint8_t *PK, const uint8_t *Gen, const uint8_t *m,
+                      size_t n, uint8_t *status, uint8_t *c_out, int threads) {
+    init_r_bytes();
+    int nt = pick_threads(threads); (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i)
+        status[i] = verify_vargen_one(u + 32 * i, R + 64 * i, PK + 64 * i, Gen + 64 * i, m + 32 * i,
+                                      c_out ? c_out + 32 * i : 0);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ signing (input generation) */
+static void store_affine(uint8_t *out, const ext_t *p) {
+    fe u, v;
+    ext_to_affine(&u, &v, p);
+    fq_to_bytes(out, &u);
+    fq_to_bytes(out + 32, &v);
+}
+static void affine_fe(fe out[2], const ext_t *p) { ext_to_affine(&out[0], &out[1], p); }
+static void small_fe(fe *o, uint64_t x) {
+    uint64_t t[4] = {x, 0, 0, 0};
+    mont_mul(o->l, t, JJO_Q_R2, JJO_Q, JJO_Q_INV);
+}
+/* u = r - c*sk mod r_order, all canonical LE bytes */
+static void response(uint8_t *u_out, const uint8_t r[32], const uint8_t c[32], const uint8_t sk[32]) {
+    uint64_t rr[4], cc[4], ss[4], t[4];
+    load_le(rr, r); load_le(cc, c); load_le(ss, sk);
+    fr_mul_canon(t, cc, ss);
+    fr_sub_canon(t, rr, t);
+    store_le(u_out, t);
+}
+
+int jjo_sign_single(const uint8_t *sk, const uint8_t *rnd, const uint8_t *m, size_t n, uint8_t *u_out,
+                    uint8_t *R_out, uint8_t *PK_out, int threads) {
+    int nt = pick_threads(threads); (void)nt;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        ext_t g, gn, R, PK;
+        gen_points(&g, &gn);
+        fe in[5], t[2], h;
+        uint8_t r[32], c[32];
+        if (!fq_from_bytes(&in[0], rnd + 32 * i) || !fq_from_bytes(&in[1], sk + 32 * i) ||
+            !fq_from_bytes(&in[3], m + 32 * i) || !scalar_canonical(sk + 32 * i)) { bad |= 1; continue; }
+        small_fe(&in[2], 1);
+        poseidon_digest(&h, in, 4);
+        truncate250(r, &h);
+        ext_mul(&R, &g, r);
+        ext_mul(&PK, &g, sk + 32 * i);
+        affine_fe(t, &R); in[0] = t[0]; in[1] = t[1];
+        affine_fe(t, &PK); in[2] = t[0]; in[3] = t[1];
+        fq_from_bytes(&in[4], m + 32 * i);
+        poseidon_digest(&h, in, 5);
+        truncate250(c, &h);
+        response(u_out + 32 * i, r, c, sk + 32 * i);
+        store_affine(R_out + 64 * i, &R);
+        store_affine(PK_out + 64 * i, &PK);
+    }
+    return bad ? -1 : 0;
+}
+int jjo_sign_double(const uint8_t *sk, const uint8_t *rnd, const uint8_t *m, size_t n, uint8_t *u_out,
+                    uint8_t *R_out, uint8_t *Rp_out, uint8_t *PK_out, uint8_t *PKp_out, int threads) {
+    int nt = pick_threads(threads); (void)nt;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        ext_t g, gn, R, Rp, PK, PKp;
+        gen_points(&g, &gn);
+        fe in[10], t[2], h;
+        uint8_t r[32], c[32];
+        if (!fq_from_bytes(&in[0], rnd + 32 * i) || !fq_from_bytes(&in[1], sk + 32 * i) ||
+            !fq_from_bytes(&in[3], m + 32 * i) || !scalar_canonical(sk + 32 * i)) { bad |= 1; continue; }
+        small_fe(&in[2], 2);
+        poseidon_digest(&h, in, 4);
+        truncate250(r, &h);
+        ext_mul(&R, &g, r); ext_mul(&Rp, &gn, r);
+        ext_mul(&PK, &g, sk + 32 * i); ext_mul(&PKp, &gn, sk + 32 * i);
+        in[0] = *(const fe *)JJO_DOUBLE_TAG_M;
+        affine_fe(t, &R); in[1] = t[0]; in[2] = t[1];
+        affine_fe(t, &Rp); in[3] = t[0]; in[4] = t[1];
+        affine_fe(t, &PK); in[5] = t[0]; in[6] = t[1];
+        affine_fe(t, &PKp); in[7] = t[0]; in[8] = t[1];
+        fq_from_bytes(&in[9], m + 32 * i);
+        poseidon_digest(&h, in, 10);
+        truncate250(c, &h);
+        response(u_out + 32 * i, r, c, sk + 32 * i);
+        store_affine(R_out + 64 * i, &R); store_affine(Rp_out + 64 * i, &Rp);
+        store_affine(PK_out + 64 * i, &PK); store_affine(PKp_out + 64 * i, &PKp);
+    }
+    return bad ? -1 : 0;
+}
+/* generator = g*G with g a canonical scalar; pk = sk*generator */
+int jjo_sign_vargen(const uint8_t *sk, const uint8_t *gsc, const uint8_t *rnd, const uint8_t *m, size_t n,
+                    uint8_t *u_out, uint8_t *R_out, uint8_t *PK_out, uint8_t *Gen_out, int threads) {
+    int nt = pick_threads(threads); (void)nt;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        ext_t g, gn, gen, gena, R, PK;
+        gen_points(&g, &gn);
+        fe in[7], t[2], h, gu, gv;
+        uint8_t r[32], c[32];
+        if (!fq_from_bytes(&in[0], rnd + 32 * i) || !fq_from_bytes(&in[1], sk + 32 * i) ||
+            !fq_from_bytes(&in[4], m + 32 * i) || !scalar_canonical(sk + 32 * i) ||
+            !scalar_canonical(gsc + 32 * i)) { bad |= 1; continue; }
+        ext_mul(&gen, &g, gsc + 32 * i);
+        ext_to_affine(&gu, &gv, &gen);
+        ext_from_affine(&gena, &gu, &gv);
+        in[2] = gu; in[3] = gv;
+        poseidon_digest(&h, in, 5);
+        truncate250(r, &h);
+        ext_mul(&R, &gena, r);
+        ext_mul(&PK, &gena, sk + 32 * i);
+        affine_fe(t, &R); in[0] = t[0]; in[1] = t[1];
+        affine_fe(t, &PK); in[2] = t[0]; in[3] = t[1];
+        in[4] = gu; in[5] = gv;
+        fq_from_bytes(&in[6], m + 32 * i);
+        poseidon_digest(&h, in, 7);
+        truncate250(c, &h);
+        response(u_out + 32 * i, r, c, sk + 32 * i);
+        store_affine(R_out + 64 * i, &R);
+        store_affine(PK_out + 64 * i, &PK);
+        store_affine(Gen_out + 64 * i, &gena);
+    }
+    return bad ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------ primitives for unit tests */
+int jjo_fq_mul(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) {
+        fe x, y, z;
+        if (!fq_from_bytes(&x, a + 32 * i) || !fq_from_bytes(&y, b + 32 * i)) return -1;
+        fq_mul(&z, &x, &y);
+        fq_to_bytes(out + 32 * i, &z);
+    }
+    return 0;
+}
+/* out = untruncated digest of k inputs per item */
+int jjo_poseidon(const uint8_t *inputs, size_t k, size_t n, uint8_t *out, int threads) {
+    if (k < 1 || k > JJO_MAX_INPUTS) return -1;
+    int nt = pick_threads(threads); (void)nt;
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        fe in[JJO_MAX_INPUTS], h;
+        int ok = 1;
+        for (size_t j = 0; j < k; ++j) ok &= fq_from_bytes(&in[j], inputs + 32 * (k * i + j));
+        if (!ok) { bad |= 1; continue; }
+        poseidon_digest(&h, in, k);
+        fq_to_bytes(out + 32 * i, &h);
+    }
+    return bad ? -1 : 0;
+}
+int jjo_scalar_mul(const uint8_t *P, const uint8_t *k, size_t n, uint8_t *out, int threads) {
+    int nt = pick_threads(threads); (void)nt;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        ext_t p, r;
+        if (!load_point(&p, P + 64 * i)) { bad |= 1; continue; }
+        ext_mul(&r, &p, k + 32 * i);
+        store_affine(out + 64 * i, &r);
+    }
+    return bad ? -1 : 0;
+}
+/* out bit0 = on_curve, bit1 = torsion_free, bit2 = identity, 0xff = non-canonical */
+int jjo_point_flags(const uint8_t *P, size_t n, uint8_t *out, int threads) {
+    init_r_bytes();
+    int nt = pick_threads(threads); (void)nt;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (long i = 0; i < (long)n; ++i) {
+        ext_t p, rp;
+        if (!load_point(&p, P + 64 * i)) { out[i] = 0xff; continue; }
+        ext_mul(&rp, &p, R_BYTES);
+        out[i] = (uint8_t)(affine_on_curve(&p.u, &p.v) | (ext_is_identity(&rp) << 1) | (ext_is_identity(&p) << 2));
+    }
+    return 0;
+}
+int jjo_point_add(const uint8_t *P, const uint8_t *Qp, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) {
+        ext_t p, q, r;
+        if (!load_point(&p, P + 64 * i) || !load_point(&q, Qp + 64 * i)) return -1;
+        ext_add(&r, &p, &q);
+        store_affine(out + 64 * i, &r);
+    }
+    return 0;
+}

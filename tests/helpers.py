@@ -1,0 +1,186 @@
+"""Shared test helpers: byte packing and deterministic batch builders (oracle-side)."""
+from __future__ import annotations
+
+import numpy as np
+
+import jjs_oracle as o
+import jjs_oracle_c as oc
+
+SEED = 0x6A6A73
+
+
+def fe_bytes(x: int) -> np.ndarray:
+    return np.frombuffer(o.le32(x), np.uint8).copy()
+
+
+def pt_bytes(p) -> np.ndarray:
+    return np.frombuffer(o.le32(p[0]) + o.le32(p[1]), np.uint8).copy()
+
+
+def fe_arr(xs) -> np.ndarray:
+    return np.stack([fe_bytes(x) for x in xs]) if len(xs) else np.zeros((0, 32), np.uint8)
+
+
+def pt_arr(ps) -> np.ndarray:
+    return np.stack([pt_bytes(p) for p in ps]) if len(ps) else np.zeros((0, 64), np.uint8)
+
+
+def to_int(row) -> int:
+    return int.from_bytes(np.asarray(row, np.uint8).tobytes(), "little")
+
+
+def to_pt(row):
+    b = np.asarray(row, np.uint8).tobytes()
+    return (int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little"))
+
+
+def rand_mod(rng: np.random.Generator, n: int, mod: int, nonzero=False) -> np.ndarray:
+    out = np.empty((n, 32), np.uint8)
+    for i in range(n):
+        x = int.from_bytes(rng.bytes(48), "little") % mod
+        if nonzero and x == 0:
+            x = 1
+        out[i] = fe_bytes(x)
+    return out
+
+
+ORDER2 = pt_bytes(o.ORDER2)
+IDENT = pt_bytes(o.IDENTITY)
+
+
+def _add_order2(points: np.ndarray) -> np.ndarray:
+    return oc.point_add(points, np.tile(ORDER2, (len(points), 1)))
+
+
+def torsion_generator():
+    """A point of exact order 8 (the 2-Sylow subgroup of JubJub is cyclic of order 8)."""
+    v = 2
+    while True:
+        b = bytearray(o.le32(v))
+        p = o.decompress(bytes(b))
+        if p is not None:
+            t = o.mul(p, o.R_ORDER)
+            if o.mul(t, 4) != o.IDENTITY:
+                return t
+        v += 1
+
+
+def make_batch(scheme: str, n: int, seed: int = SEED, n_keys: int = 64, mix: bool = True):
+    """Deterministic synthetic batch: K distinct keys, item i uses key i mod K,
+    uniform messages, oracle signatures, then a fixed mix of corruptions.  Returns a dict of
+    numpy arrays keyed by ABI argument name."""
+    rng = np.random.default_rng(seed)
+    K = max(1, min(n_keys, n))
+    sk_k = rand_mod(rng, K, o.R_ORDER, nonzero=True)
+    g_k = rand_mod(rng, K, o.R_ORDER, nonzero=True)
+    idx = np.arange(n) % K
+    sk = sk_k[idx]
+    rnd = rand_mod(rng, n, o.R_ORDER)
+    m = rand_mod(rng, n, o.Q)
+    if scheme == "single":
+        u, R, PK = oc.sign_single(sk, rnd, m)
+        b = {"u": u, "R": R, "PK": PK, "m": m}
+        pts_pk, pts_r = ["PK"], ["R"]
+    elif scheme == "double":
+        u, R, Rp, PK, PKp = oc.sign_double(sk, rnd, m)
+        b = {"u": u, "R": R, "Rp": Rp, "PK": PK, "PKp": PKp, "m": m}
+        pts_pk, pts_r = ["PK", "PKp"], ["R", "Rp"]
+    elif scheme == "vargen":
+        u, R, PK, Gen = oc.sign_vargen(sk, g_k[idx], rnd, m)
+        b = {"u": u, "R": R, "PK": PK, "Gen": Gen, "m": m}
+        pts_pk, pts_r = ["PK", "Gen"], ["R"]
+    else:
+        raise ValueError(scheme)
+    if not mix or n == 0:
+        return b
+    sel = rng.integers(0, 256, size=n)
+    # 15/16 valid; 1/32 wrong key; 1/64 tampered m; 1/128 identity; 1/256 order-2; 1/256 mixed order
+    wrong_key = np.where(sel < 8)[0]
+    tamper = np.where((sel >= 8) & (sel < 12))[0]
+    ident = np.where((sel >= 12) & (sel < 14))[0]
+    ord2 = np.where(sel == 14)[0]
+    mixed = np.where(sel == 15)[0]
+    if len(wrong_key):
+        # signature made with another key -> equation fails
+        other = np.roll(np.arange(n), 1)[wrong_key]
+        for name in pts_pk[:1]:
+            b[name][wrong_key] = b[name][other]
+        # make sure "other" is really a different key
+        same = (idx[wrong_key] == idx[other])
+        if same.any():
+            b["u"][wrong_key[same], 0] ^= 1
+    if len(tamper):
+        b["m"][tamper, 0] ^= 1
+        # keep canonical: clear the top byte's high bits
+        b["m"][tamper, 31] &= 0x3F
+    for j, i in enumerate(ident):
+        b[(pts_pk + pts_r)[j % len(pts_pk + pts_r)]][i] = IDENT
+    for j, i in enumerate(ord2):
+        b[(pts_pk + pts_r)[j % len(pts_pk + pts_r)]][i] = ORDER2
+    if len(mixed):
+        for j, name in enumerate(pts_pk + pts_r):
+            rows = mixed[j :: len(pts_pk + pts_r)]
+            if len(rows):
+                b[name][rows] = _add_order2(b[name][rows])
+    return b
+
+
+ARG_ORDER = {
+    "single": ["u", "R", "PK", "m"],
+    "double": ["u", "R", "Rp", "PK", "PKp", "m"],
+    "vargen": ["u", "R", "PK", "Gen", "m"],
+}
+
+
+def oracle_verify(scheme: str, b: dict, threads: int = 0, want_c: bool = False):
+    fn = {"single": oc.verify_single, "double": oc.verify_double, "vargen": oc.verify_vargen}[scheme]
+    return fn(*[b[k] for k in ARG_ORDER[scheme]], threads=threads, want_c=want_c)
+
+
+def py_verify(scheme: str, b: dict, i: int) -> int:
+    if scheme == "single":
+        return o.verify_single(to_int(b["u"][i]), to_pt(b["R"][i]), to_pt(b["PK"][i]), to_int(b["m"][i]))
+    if scheme == "double":
+        return o.verify_double(to_int(b["u"][i]), to_pt(b["R"][i]), to_pt(b["Rp"][i]), to_pt(b["PK"][i]),
+                               to_pt(b["PKp"][i]), to_int(b["m"][i]))
+    return o.verify_vargen(to_int(b["u"][i]), to_pt(b["R"][i]), to_pt(b["PK"][i]), to_pt(b["Gen"][i]),
+                           to_int(b["m"][i]))
+
+
+def edge_cases(scheme: str):
+    """Hand-built adversarial items, each with the status the Python oracle assigns."""
+    base = make_batch(scheme, 1, seed=7, mix=False)
+    items = []
+
+    def variant(**over):
+        d = {k: v[0].copy() for k, v in base.items()}
+        d.update(over)
+        items.append(d)
+
+    variant()
+    pts = [k for k in ARG_ORDER[scheme] if k not in ("u", "m")]
+    for name in pts:
+        variant(**{name: IDENT})
+        variant(**{name: ORDER2})
+        variant(**{name: _add_order2(base[name])[0]})
+        off = base[name][0].copy(); off[32] ^= 1            # v changed -> off curve
+        variant(**{name: off})
+        nc = base[name][0].copy(); nc[:32] = fe_bytes(o.Q)   # u = q (non-canonical)
+        variant(**{name: nc})
+        nc2 = base[name][0].copy(); nc2[32:] = 0xFF          # v = 2^256-1
+        variant(**{name: nc2})
+    # points of order 8 and 4, and subgroup point + each torsion point
+    t8 = torsion_generator()
+    variant(**{pts[0]: pt_bytes(t8)})
+    variant(**{pts[0]: pt_bytes(o.mul(t8, 2))})
+    for k in range(1, 8):
+        variant(**{pts[-1]: pt_bytes(o.add(to_pt(base[pts[-1]][0]), o.mul(t8, k)))})
+    variant(u=fe_bytes(o.R_ORDER))
+    variant(u=fe_bytes(o.R_ORDER - 1))
+    variant(u=fe_bytes(0))
+    variant(m=fe_bytes(o.Q))
+    variant(m=fe_bytes(o.Q - 1))
+    variant(m=fe_bytes(0))
+    variant(u=np.full(32, 0xFF, np.uint8))
+    b = {k: np.stack([it[k] for it in items]) for k in base}
+    return b
