@@ -1,0 +1,71 @@
+// Width-5 Hades permutation + SAFE sponge: `Hash::digest_truncated(Domain::Other, inputs)[0]`.
+//
+// Replaces dusk-poseidon 0.42.0-rc.0 (+ dusk-safe) as called at /root/reference/src/signatures.rs:130,
+// src/signatures/double.rs:162 and src/signatures/var_gen.rs:130.  Parameterisation per SURVEY.md A.3:
+// 4 full + 60 partial + 4 full rounds, S-box x^5 on state[4] in partial rounds, round constants and
+// Cauchy matrix as generated into jjs_constants.inc.  Constants are read at wave-uniform addresses
+// (scalar cache, SGPR operands); each matrix row is ONE five-term dot product with a single
+// Montgomery reduction (fq_dot_const) instead of five reduced products.
+#pragma once
+#include "fq29.h"
+
+namespace jjs {
+
+struct hades_state {
+    fe_n s[5];
+};
+
+template <int L, int A>
+JJS_HD fe_n sbox5(const fe<L, A>& x) {
+    fe_n x2 = fq_sqr(x);
+    fe_n x4 = fq_sqr(x2);
+    return fq_mul(x4, x);
+}
+
+JJS_HD void hades_permute(hades_state& st) {
+    for (int rnd = 0; rnd < 68; ++rnd) {
+        const bool full = (rnd < 4) || (rnd >= 64);
+        fe<1, 3> t[5];
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                t[i] = fq_as<1, 3>(sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i]))));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i])));
+        }
+        t[4] = fq_as<1, 3>(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_RC[5 * rnd + 4]))));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st.s[i] = fq_dot_const<5, 3>(JJS_MDS[i], t);
+    }
+}
+
+// Absorbs n_inputs elements fetched through `fetch(e)` (which returns the Montgomery form of
+// transcript element e) and squeezes one element.  The sponge is processed in rate-4 blocks so that
+// the permutation has a single call site and no input has to stay live across a permutation.
+template <typename Fetch>
+JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch) {
+    hades_state st;
+    st.s[0] = fq_as<1, 2>(fe_from_const<1, 1>(JJS_SPONGE_TAG[n_inputs]));
+#pragma unroll
+    for (int i = 1; i < 5; ++i) st.s[i] = fq_as<1, 2>(fq_zero());
+    const int n_blocks = (n_inputs + 3) >> 2;
+    for (int blk = 0; blk < n_blocks; ++blk) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int e = 4 * blk + k;
+            if (e < n_inputs) st.s[1 + k] = fq_reduce(fq_norm(fq_add(st.s[1 + k], fetch(e))));
+        }
+        hades_permute(st);
+    }
+    return st.s[1];
+}
+
+// digest -> canonical words, low 250 bits (JubJubScalar)
+JJS_HD words8 truncate250(const fe_n& digest) {
+    words8 c = fq_to_words(digest);
+    c.w[7] &= 0x03ffffffu;
+    return c;
+}
+
+}  // namespace jjs

@@ -1,0 +1,136 @@
+// CPU build of the SAME arithmetic / verification source the HIP kernels compile
+// (jubjub_schnorr_amd/csrc/*.h), for `-m "not gpu"` tests and sanitizer runs.  Test
+// infrastructure: the product library (libjjs_gpu.so) never contains or calls this.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "schemes.h"
+
+using namespace jjs;
+
+static std::vector<uint32_t> g_comb_g, g_comb_gn;
+alignas(16) static uint32_t g_tag[8];
+
+static void ensure_tables() {
+    if (!g_comb_g.empty()) return;
+    g_comb_g.resize(COMB_TABLE_WORDS);
+    g_comb_gn.resize(COMB_TABLE_WORDS);
+    for (int i = 0; i < COMB_WINDOWS; ++i)
+        for (int b = 0; b < COMB_ENTRIES; ++b) {
+            build_comb_entry(g_comb_g.data(), JJS_G, i, b);
+            build_comb_entry(g_comb_gn.data(), JJS_GN, i, b);
+        }
+    memcpy(g_tag, JJS_DOUBLE_TAG_WORDS, 32);
+}
+
+static void run(verify_params P) {
+    std::vector<uint32_t> ws(WS_WORDS_PER_LANE + 4);
+    uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+    for (uint64_t i = 0; i < P.n; ++i) {
+        uint32_t st = verify_item(P, i, w);
+        if (P.status) P.status[i] = (uint8_t)st;
+        if (P.tally) P.tally[st]++;
+    }
+}
+
+extern "C" {
+
+int jjs_host_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 x, y;
+        memcpy(x.w, a + 32 * i, 32); memcpy(y.w, b + 32 * i, 32);
+        fe_n r = fq_mul(fq_from_words(x), fq_from_words(y));
+        words8 o = fq_to_words(r);
+        memcpy(out + 32 * i, o.w, 32);
+    }
+    return 0;
+}
+int jjs_host_fq_sqr(const uint8_t* a, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 x;
+        memcpy(x.w, a + 32 * i, 32);
+        words8 o = fq_to_words(fq_sqr(fq_from_words(x)));
+        memcpy(out + 32 * i, o.w, 32);
+    }
+    return 0;
+}
+// out = a - b, a + b (64 bytes per item), through the lazy add/sub/norm/reduce path
+int jjs_host_fq_addsub(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 x, y;
+        memcpy(x.w, a + 32 * i, 32); memcpy(y.w, b + 32 * i, 32);
+        fe_n fx = fq_from_words(x), fy = fq_from_words(y);
+        words8 d = fq_to_words(fq_norm(fq_sub(fx, fy)));
+        words8 s = fq_to_words(fq_reduce(fq_norm(fq_add(fx, fy))));
+        memcpy(out + 64 * i, d.w, 32); memcpy(out + 64 * i + 32, s.w, 32);
+    }
+    return 0;
+}
+int jjs_host_fq_inv(const uint8_t* a, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 x;
+        memcpy(x.w, a + 32 * i, 32);
+        words8 o = fq_to_words(fq_inverse(fq_from_words(x)));
+        memcpy(out + 32 * i, o.w, 32);
+    }
+    return 0;
+}
+int jjs_host_poseidon(const uint8_t* in, size_t k, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        fe_n d = poseidon_digest((int)k, [&](int e) {
+            words8 x;
+            memcpy(x.w, in + 32 * (k * i + e), 32);
+            return fq_from_words(x);
+        });
+        words8 o = fq_to_words(d);
+        memcpy(out + 32 * i, o.w, 32);
+    }
+    return 0;
+}
+// bit0 on_curve, bit1 torsion_free, bit2 identity
+int jjs_host_point_flags(const uint8_t* P, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 x, y;
+        memcpy(x.w, P + 64 * i, 32); memcpy(y.w, P + 64 * i + 32, 32);
+        fe_n u = fq_from_words(x), v = fq_from_words(y);
+        out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | (is_torsion_free(u, v) ? 2 : 0) | (affine_is_identity(u, v) ? 4 : 0));
+    }
+    return 0;
+}
+// comb table entry -> affine point bytes (u || v), recovered from the cached form
+int jjs_host_comb_entry(int which, int i, int b, uint8_t* out_ypx_ymx_t2d) {
+    ensure_tables();
+    const uint32_t* t = (which ? g_comb_gn.data() : g_comb_g.data()) + ((size_t)i * COMB_ENTRIES + b) * COMB_ENTRY_WORDS;
+    for (int c = 0; c < 3; ++c) {
+        fe_n f;
+        for (int k = 0; k < 9; ++k) f.l[k] = t[9 * c + k];
+        words8 o = fq_to_words(f);
+        memcpy(out_ypx_ymx_t2d + 32 * c, o.w, 32);
+    }
+    return 0;
+}
+int jjs_host_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                           uint8_t* status, uint64_t* tally, uint8_t* c_out) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run(params_single(u, R, PK, m, n, g_comb_g.data(), out_ptrs{status, t, c_out, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+int jjs_host_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                           const uint8_t* m, size_t n, uint8_t* status, uint64_t* tally, uint8_t* c_out) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run(params_double(u, R, Rp, PK, PKp, m, n, (const uint8_t*)g_tag, g_comb_g.data(), g_comb_gn.data(),
+                      out_ptrs{status, t, c_out, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+int jjs_host_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                           size_t n, uint8_t* status, uint64_t* tally, uint8_t* c_out) {
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run(params_vargen(u, R, PK, Gen, m, n, out_ptrs{status, t, c_out, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+}

@@ -1,0 +1,86 @@
+"""ctypes loader for tests/hostbuild/libjjs_hosttest.so: the product's csrc/*.h compiled for the CPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "hostbuild", "host_harness.cpp")
+LIB = os.path.join(HERE, "hostbuild", "libjjs_hosttest.so")
+CSRC = os.path.join(ROOT, "jubjub_schnorr_amd", "csrc")
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _stale():
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas",
+                               "-I" + CSRC, "-o", LIB, SRC])
+    _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def fq_mul(a, b):
+    a, b = _c(a), _c(b); out = np.empty_like(a)
+    load().jjs_host_fq_mul(_p(a), _p(b), ctypes.c_size_t(len(a)), _p(out)); return out
+
+
+def fq_sqr(a):
+    a = _c(a); out = np.empty_like(a)
+    load().jjs_host_fq_sqr(_p(a), ctypes.c_size_t(len(a)), _p(out)); return out
+
+
+def fq_inv(a):
+    a = _c(a); out = np.empty_like(a)
+    load().jjs_host_fq_inv(_p(a), ctypes.c_size_t(len(a)), _p(out)); return out
+
+
+def fq_addsub(a, b):
+    a, b = _c(a), _c(b); out = np.empty((len(a), 64), np.uint8)
+    load().jjs_host_fq_addsub(_p(a), _p(b), ctypes.c_size_t(len(a)), _p(out)); return out[:, :32], out[:, 32:]
+
+
+def poseidon(x):
+    x = _c(x); n, k, _ = x.shape; out = np.empty((n, 32), np.uint8)
+    load().jjs_host_poseidon(_p(x), ctypes.c_size_t(k), ctypes.c_size_t(n), _p(out)); return out
+
+
+def point_flags(P):
+    P = _c(P); out = np.empty(len(P), np.uint8)
+    load().jjs_host_point_flags(_p(P), ctypes.c_size_t(len(P)), _p(out)); return out
+
+
+def comb_entry(which, i, b):
+    out = np.empty(96, np.uint8)
+    load().jjs_host_comb_entry(which, i, b, _p(out)); return out
+
+
+def verify(scheme, b, want_c=False):
+    from helpers import ARG_ORDER
+    args = [_c(b[k]) for k in ARG_ORDER[scheme]]
+    n = len(args[0])
+    st = np.empty(n, np.uint8); tally = np.zeros(4, np.uint64)
+    c = np.zeros((n, 32), np.uint8) if want_c else None
+    fn = getattr(load(), "jjs_host_verify_" + scheme)
+    fn(*[_p(a) for a in args], ctypes.c_size_t(n), _p(st), _p(tally), _p(c))
+    return (st, tally, c) if want_c else (st, tally)

@@ -1,0 +1,77 @@
+"""The product's arithmetic and verification source (jubjub_schnorr_amd/csrc/*.h) compiled for the
+CPU and checked against the oracle.  The GPU tests (-m gpu) check the same source as HIP kernels."""
+import numpy as np
+import pytest
+
+import hostlib as hl
+import jjs_oracle as o
+import jjs_oracle_c as oc
+from helpers import edge_cases, fe_arr, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator
+
+
+def special_fq(rng, n):
+    a = rand_mod(rng, n, o.Q)
+    specials = [0, 1, 2, o.Q - 1, o.Q - 2, (1 << 255) % o.Q, (1 << 261) % o.Q, (1 << 29) - 1, (1 << 232), (o.Q + 1) // 2]
+    for i, s in enumerate(specials):
+        a[i] = fe_bytes(s % o.Q)
+    return a
+
+
+def test_field_ops_match_bigint():
+    rng = np.random.default_rng(3)
+    a, b = special_fq(rng, 256), special_fq(rng, 256)[::-1].copy()
+    prod = hl.fq_mul(a, b); sq = hl.fq_sqr(a); d, s = hl.fq_addsub(a, b)
+    for i in range(len(a)):
+        x, y = to_int(a[i]), to_int(b[i])
+        assert to_int(prod[i]) == x * y % o.Q
+        assert to_int(sq[i]) == x * x % o.Q
+        assert to_int(d[i]) == (x - y) % o.Q
+        assert to_int(s[i]) == (x + y) % o.Q
+    inv = hl.fq_inv(a[:16])
+    for i in range(16):
+        x = to_int(a[i])
+        assert to_int(inv[i]) == (pow(x, o.Q - 2, o.Q) if x else 0)
+
+
+def test_poseidon_matches_oracle():
+    rng = np.random.default_rng(4)
+    for k in (1, 4, 5, 7, 8, 10, 15):
+        x = rand_mod(rng, 4 * k, o.Q).reshape(4, k, 32)
+        x[0, :, :] = fe_bytes(o.Q - 1)
+        assert (hl.poseidon(x) == oc.poseidon(x)).all()
+
+
+def test_point_flags_all_cosets():
+    t8 = torsion_generator()
+    s = o.mul(o.G, 987654321)
+    pts = [o.add(s, o.mul(t8, k)) for k in range(8)] + [o.mul(t8, k) for k in range(8)] + [(5, 7)]
+    assert (hl.point_flags(pt_arr(pts)) == oc.point_flags(pt_arr(pts))).all()
+
+
+def test_comb_tables_are_multiples_of_generators():
+    for which, base in ((0, o.G), (1, o.G_NUMS)):
+        for i, b in ((0, 0), (0, 1), (0, 255), (1, 1), (7, 200), (31, 1), (31, 15)):
+            p = o.mul(base, b << (8 * i)) if b else o.IDENTITY
+            e = hl.comb_entry(which, i, b)
+            ypx, ymx, t2d = (to_int(e[32 * k:32 * k + 32]) for k in range(3))
+            assert ypx == (p[1] + p[0]) % o.Q and ymx == (p[1] - p[0]) % o.Q
+            assert t2d == 2 * o.D * p[0] * p[1] % o.Q
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_verify_matches_oracle_on_mixed_batch(scheme):
+    b = make_batch(scheme, 80, seed=21, n_keys=8)
+    want, want_c = oracle_verify(scheme, b, want_c=True)
+    st, tally, c = hl.verify(scheme, b, want_c=True)
+    assert st.tolist() == want.tolist()
+    assert (c == want_c).all()
+    assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    assert len(set(want.tolist())) >= 3
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_verify_matches_oracle_on_edge_cases(scheme):
+    b = edge_cases(scheme)
+    want = oracle_verify(scheme, b)
+    st, _ = hl.verify(scheme, b)
+    assert st.tolist() == want.tolist()
