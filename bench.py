@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark: Schnorr-on-JubJub batch verification throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme single|double|vargen]
+                    [--log2-items-per-gpu 20] [--no-cpu-baseline]
+
+One "step" = one pass of the verify hot path over one batch of synthetic signatures that is
+already resident in HBM (BASELINE.json configs[1]: 2^20 single signatures on one MI355X).  For
+N > 1 the driver launches one process per GPU (torch.distributed.run); every rank verifies its own
+2^20-item shard and the only exchange is an RCCL all-reduce of the 4-counter tally, inside the
+timed region.  Rank 0 prints ONE JSON line.
+
+Synthetic inputs: seed 0x6a6a73, 4096 distinct keys, item i signed with key i mod
+4096 by the library's own GPU signer (tests pin it bit-exact to the oracle), then 15/16 valid,
+1/32 wrong key, 1/64 tampered message, 1/128 identity PK, 1/256 order-2 PK, 1/256 mixed-order PK.
+The expected status of every item is known by construction and is checked (bit-exact) every run.
+
+The oracle (oracle/) is used here only as `cpu_baseline`: the C restatement of the reference's
+algorithm timed on the host cores over a bounded sample of the same batch, whose statuses are also
+compared with the GPU's.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x6A6A73
+N_KEYS = 4096
+ALGO_BYTES = {"single": 196, "double": 324, "vargen": 260}   # bytes in + status out per verify
+HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+ARG_ORDER = {"single": ["u", "R", "PK", "m"], "double": ["u", "R", "Rp", "PK", "PKp", "m"],
+             "vargen": ["u", "R", "PK", "Gen", "m"]}
+
+
+def make_inputs(eng, scheme: str, n: int, rank: int):
+    """Returns (dict of CUDA uint8 tensors, expected status tensor)."""
+    import torch
+    gen = torch.Generator(device="cpu").manual_seed(SEED + 7919 * rank)
+
+    def rand_bytes(rows, top_mask):
+        t = torch.randint(0, 256, (rows, 32), dtype=torch.uint8, generator=gen)
+        t[:, 31] &= top_mask
+        return t
+
+    key_sk = rand_bytes(N_KEYS, 0x07); key_sk[:, 0] |= 1     # < 2^251 < r, non-zero
+    key_g = rand_bytes(N_KEYS, 0x07); key_g[:, 0] |= 1
+    kidx = torch.arange(n) % N_KEYS
+    sk = key_sk[kidx].cuda()
+    g = key_g[kidx].cuda()
+    rnd = rand_bytes(n, 0x07).cuda()
+    m = rand_bytes(n, 0x3F).cuda()                           # < 2^254 < q
+    if scheme == "single":
+        u, R, PK = eng.sign(scheme, sk, rnd, m)
+        a = {"u": u, "R": R, "PK": PK, "m": m}
+    elif scheme == "double":
+        u, R, Rp, PK, PKp = eng.sign(scheme, sk, rnd, m)
+        a = {"u": u, "R": R, "Rp": Rp, "PK": PK, "PKp": PKp, "m": m}
+    else:
+        u, R, PK, Gen = eng.sign(scheme, sk, rnd, m, gen_scalar=g)
+        a = {"u": u, "R": R, "PK": PK, "Gen": Gen, "m": m}
+    torch.cuda.synchronize()
+
+    sel = torch.randint(0, 256, (n,), generator=gen).cuda()
+    idx = torch.arange(n, device="cuda")
+    expect = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    # 1/32 wrong key: PK of the next key (a different key since N_KEYS > 1)
+    wrong = sel < 8
+    if n > 1:
+        a["PK"] = torch.where(wrong[:, None], a["PK"][(idx + 1) % n], a["PK"])
+        expect[wrong] = 2
+    # 1/64 tampered message
+    tam = (sel >= 8) & (sel < 12)
+    a["m"] = a["m"].clone(); a["m"][tam, 0] ^= 1
+    expect[tam] = 2
+    # 1/128 identity PK, 1/256 order-2 PK, 1/256 mixed-order PK (P + (0,-1) = (-u, -v))
+    ident = torch.zeros(64, dtype=torch.uint8); ident[32] = 1
+    order2 = torch.tensor(list((0).to_bytes(32, "little") + (Q - 1).to_bytes(32, "little")), dtype=torch.uint8)
+    idm = (sel >= 12) & (sel < 14)
+    o2m = sel == 14
+    mxm = sel == 15
+    a["PK"][idm] = ident.cuda()
+    a["PK"][o2m] = order2.cuda()
+    rows = torch.nonzero(mxm).flatten()
+    if len(rows):
+        pk = a["PK"][rows].cpu().numpy()
+        out = pk.copy()
+        for j in range(len(rows)):
+            uu = int.from_bytes(pk[j, :32].tobytes(), "little")
+            vv = int.from_bytes(pk[j, 32:].tobytes(), "little")
+            out[j, :32] = list(((Q - uu) % Q).to_bytes(32, "little"))
+            out[j, 32:] = list(((Q - vv) % Q).to_bytes(32, "little"))
+        a["PK"][rows] = torch.from_numpy(out).cuda()
+    expect[idm | o2m | mxm] = 1
+    return {k: v.contiguous() for k, v in a.items()}, expect
+
+
+def cpu_baseline(scheme: str, arrays: dict, gpu_status, budget_s: float = 12.0):
+    """Oracle (C restatement of the reference's algorithm) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import jjs_oracle_c as oc
+    try:
+        oc.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    fn = {"single": oc.verify_single, "double": oc.verify_double, "vargen": oc.verify_vargen}[scheme]
+    threads = max(1, min(16, os.cpu_count() or 1, oc.max_threads(native)))
+    probe = 2048
+    host = {k: arrays[k][:probe].cpu().numpy() for k in ARG_ORDER[scheme]}
+    t0 = time.perf_counter()
+    fn(*[host[k] for k in ARG_ORDER[scheme]], threads=threads, native=native)
+    rate = probe / (time.perf_counter() - t0)
+    n = int(min(arrays["u"].shape[0], max(probe, rate * budget_s)))
+    host = {k: arrays[k][:n].cpu().numpy() for k in ARG_ORDER[scheme]}
+    t0 = time.perf_counter()
+    st = fn(*[host[k] for k in ARG_ORDER[scheme]], threads=threads, native=native)
+    dt = time.perf_counter() - t0
+    agree = bool((st == gpu_status[:n].cpu().numpy()).all())
+    return {"value": n / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} items of the same {scheme} batch, oracle/jjs_oracle.c "
+                      f"({'-march=native' if native else 'generic x86-64'}), {dt:.1f} s",
+            "statuses_equal_gpu": agree}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scheme", default="single", choices=["single", "double", "vargen"])
+    ap.add_argument("--log2-items-per-gpu", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import jubjub_schnorr_amd as jjs
+    eng = jjs.engine()
+    scheme = args.scheme
+    n = 1 << args.log2_items_per_gpu
+    arrays, expect = make_inputs(eng, scheme, n, rank)
+    call = [arrays[k] for k in ARG_ORDER[scheme]]
+    want_tally = torch.stack([(expect == k).sum() for k in range(4)]).to(torch.int64)
+
+    def step():
+        st, tally = eng.verify(scheme, *call)
+        if dist is not None:
+            dist.all_reduce(tally)          # RCCL over xGMI: 4 x int64, the path's only exchange
+        return st, tally
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st, tally = step()
+    fence()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st, tally_local = eng.verify(scheme, *call)
+        e1.record()
+        tally = tally_local
+        if dist is not None:
+            tally = tally_local.clone()
+            dist.all_reduce(tally)
+        evs.append((e0, e1))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
+
+    # bit-exact check against the by-construction expectation (every rank)
+    ok_status = bool(torch.equal(st, expect))
+    ok_tally = bool(torch.equal(tally_local.cpu(), want_tally.cpu()))
+    total_expected = want_tally.clone().cuda()
+    if dist is not None:
+        dist.all_reduce(total_expected)
+    ok_global = bool(torch.equal(tally.cpu(), total_expected.cpu()))
+
+    if rank == 0:
+        total_items = n * world * args.steps
+        value = total_items / elapsed
+        achieved = ALGO_BYTES[scheme] * n / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("scheme") == scheme and rec.get("items") == n:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Schnorr verifications/sec",
+            "value": value,
+            "unit": "verifications/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (29-bit), u64 accumulators",
+            "data": "synthetic",
+            "config": {"workload": f"2^{args.log2_items_per_gpu} {scheme} signatures per GPU, resident in HBM "
+                                   f"(BASELINE.json configs[{ {'single': 1, 'double': 2, 'vargen': 4}[scheme] }])",
+                       "scheme": scheme, "items_per_gpu": n, "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
+                       "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points"},
+            "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "verify_kernel", "kernel_ms": kernel_ms,
+                         "note": "integer-ALU bound path (SURVEY.md 8d): see DESIGN.md for the multiply-issue roofline"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scheme, arrays, st)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not (ok_status and ok_tally and ok_global):
+        raise SystemExit("bit-exact check failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/*
+ * libjjs_gpu -- batch Schnorr-on-JubJub verification on AMD MI355X (gfx950).
+ *
+ * C ABI that a host-language shim binds (Rust `extern "C"`, ctypes, ...).  It is the batch
+ * drop-in for the `verify` hot path of dusk-network/jubjub-schnorr:
+ *
+ *   jjs_verify_single*  <->  PublicKey::verify        reference src/keys/public.rs:114-135
+ *   jjs_verify_double*  <->  PublicKeyDouble::verify  reference src/keys/public/double.rs:86-117
+ *   jjs_verify_vargen*  <->  PublicKeyVarGen::verify  reference src/keys/public/var_gen.rs:107-133
+ *   status codes        <->  Result<(), Error>        reference src/error.rs:13-19
+ *   jjs_challenge_*     <->  challenge_hash           reference src/signatures.rs:122-140,
+ *                             src/signatures/double.rs:151-177, src/signatures/var_gen.rs:121-142
+ *   jjs_sign_*          <->  SecretKey::sign & co.    reference src/keys/secret.rs:174-194,
+ *                             src/keys/secret/double.rs:56-85, src/keys/secret/var_gen.rs:228-256
+ *                             (test-vector / benchmark-input generator: NOT constant time)
+ *
+ * Data layout (all entry points): structure of arrays, item i of an array at offset i*size.
+ *   field element / scalar : 32 bytes, little-endian, canonical (BlsScalar::to_bytes,
+ *                            JubJubScalar::to_bytes)
+ *   point                  : 64 bytes = affine u || v, each 32 bytes little-endian canonical
+ *                            (what JubJubExtended::to_hash_inputs() returns, reference
+ *                            src/signatures.rs:127-128)
+ * Every buffer must be 16-byte aligned.
+ *
+ * status[i]: 0 = Ok, 1 = InvalidPoint, 2 = InvalidSignature (reference src/error.rs:17-19 with the
+ * precedence of src/keys/public.rs:119-132), 3 = Malformed (a coordinate or message >= q, or
+ * u >= r: unreachable through the Rust types, defined so that this ABI is total).
+ * tally[k] = number of items with status k.
+ *
+ * Return value: 0 = success; negative = engine error, in which case outputs are unspecified:
+ *   -1 bad argument, -2 HIP error, -3 collective (RCCL) error, -4 not initialised.
+ * No exceptions, no aborts.  jjs_last_error() describes the last failure of the calling process.
+ *
+ * Ownership: the caller owns every buffer passed in; the library keeps nothing after a blocking
+ * call returns (after the stream has drained, for the *_dev calls).  The library owns its device
+ * tables, workspace and stream between jjs_init and jjs_shutdown.
+ *
+ * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
+ * thread and are serialised by one internal mutex (one batch in flight per process).
+ */
+#ifndef JJS_GPU_H
+#define JJS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JJS_OK 0
+#define JJS_ERR_ARG (-1)
+#define JJS_ERR_HIP (-2)
+#define JJS_ERR_COLLECTIVE (-3)
+#define JJS_ERR_NOT_INIT (-4)
+
+#define JJS_STATUS_OK 0
+#define JJS_STATUS_INVALID_POINT 1
+#define JJS_STATUS_INVALID_SIGNATURE 2
+#define JJS_STATUS_MALFORMED 3
+
+/* Binds the engine to the calling thread's current HIP device (one process per GPU), builds the
+ * fixed-base tables for G and G' on it and allocates the workspace.  `device_count` must be 0 or 1
+ * in this version (multi-GPU = one process per GPU, batches sharded by the caller, see
+ * INTEGRATION.md).  Idempotent. */
+int jjs_init(int device_count);
+void jjs_shutdown(void);
+const char* jjs_last_error(void);
+/* ABI version: bumped on any signature change. */
+int jjs_abi_version(void);
+
+/* ---- host buffers, blocking: copy in, verify, copy out -------------------------------------- */
+int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                      uint8_t* status, uint64_t tally[4]);
+int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* R_prime, const uint8_t* PK,
+                      const uint8_t* PK_prime, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]);
+int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                      size_t n, uint8_t* status, uint64_t tally[4]);
+
+/* ---- device buffers (resident data), asynchronous on `stream` ------------------------------------
+ * All pointers are device pointers on the engine's device.  `status` (n bytes) and `tally`
+ * (4 x uint64, zeroed by the call) may each be NULL.  `stream` is a hipStream_t passed as void*
+ * (NULL = the device's default stream, as in HIP).  The call enqueues and returns; use jjs_stream_sync or any
+ * HIP synchronisation on that stream before reading the outputs. */
+int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
+                          void* tally, void* stream);
+int jjs_verify_double_dev(const void* u, const void* R, const void* R_prime, const void* PK, const void* PK_prime,
+                          const void* m, size_t n, void* status, void* tally, void* stream);
+int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                          void* status, void* tally, void* stream);
+int jjs_stream_sync(void* stream);
+
+/* ---- transcript parity (debug export): c_out = n x 32 bytes, the 250-bit challenge per item ---- */
+int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_t n, void* c_out, void* stream);
+int jjs_challenge_double_dev(const void* R, const void* R_prime, const void* PK, const void* PK_prime, const void* m,
+                             size_t n, void* c_out, void* stream);
+int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* c_out,
+                             void* stream);
+
+/* ---- signing: generator of synthetic inputs (NOT constant time, not for production keys) -------
+ * sk, rnd: scalars < r; m: field element < q.  rnd is the RNG draw the reference's hedged nonce
+ * mixes in (reference src/nonce.rs:32-44).  Outputs: u (n x 32), points (n x 64 affine). */
+int jjs_sign_single_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out,
+                        void* PK_out, void* stream);
+int jjs_sign_double_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out,
+                        void* R_prime_out, void* PK_out, void* PK_prime_out, void* stream);
+/* gen_scalar: per-item generator = gen_scalar * G (reference src/keys/secret/var_gen.rs:162-172) */
+int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd, const void* m, size_t n, void* u_out,
+                        void* R_out, void* PK_out, void* Gen_out, void* stream);
+
+/* ---- primitives exposed for parity tests ------------------------------------------------------ */
+/* out[i] = a[i] * b[i] mod q (canonical bytes in and out) */
+int jjs_debug_fq_mul_dev(const void* a, const void* b, size_t n, void* out, void* stream);
+/* out[i] = untruncated Poseidon digest of the k field elements at in[(i*k + j)*32] */
+int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* stream);
+/* out[i] bit0 = on curve, bit1 = torsion free, bit2 = identity */
+int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream);
+/* copies the fixed-base table of G (which = 0) or G' (which = 1) to host memory; size in bytes via
+ * jjs_debug_comb_table_bytes() */
+size_t jjs_debug_comb_table_bytes(void);
+int jjs_debug_comb_table(int which, void* host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JJS_GPU_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of libjjs_gpu.so (the C ABI declared in include/jjs_gpu.h).
+
+There is no fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjjs_gpu.so")
+
+_P, _Z, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/jjs_gpu.h
+SIGNATURES = {
+    "jjs_init": [_I],
+    "jjs_shutdown": [],
+    "jjs_last_error": [],
+    "jjs_abi_version": [],
+    "jjs_verify_single": [_P, _P, _P, _P, _Z, _P, _P],
+    "jjs_verify_double": [_P, _P, _P, _P, _P, _P, _Z, _P, _P],
+    "jjs_verify_vargen": [_P, _P, _P, _P, _P, _Z, _P, _P],
+    "jjs_verify_single_dev": [_P, _P, _P, _P, _Z, _P, _P, _P],
+    "jjs_verify_double_dev": [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _P],
+    "jjs_verify_vargen_dev": [_P, _P, _P, _P, _P, _Z, _P, _P, _P],
+    "jjs_stream_sync": [_P],
+    "jjs_challenge_single_dev": [_P, _P, _P, _Z, _P, _P],
+    "jjs_challenge_double_dev": [_P, _P, _P, _P, _P, _Z, _P, _P],
+    "jjs_challenge_vargen_dev": [_P, _P, _P, _P, _Z, _P, _P],
+    "jjs_sign_single_dev": [_P, _P, _P, _Z, _P, _P, _P, _P],
+    "jjs_sign_double_dev": [_P, _P, _P, _Z, _P, _P, _P, _P, _P, _P],
+    "jjs_sign_vargen_dev": [_P, _P, _P, _P, _Z, _P, _P, _P, _P, _P],
+    "jjs_debug_fq_mul_dev": [_P, _P, _Z, _P, _P],
+    "jjs_debug_poseidon_dev": [_P, _Z, _Z, _P, _P],
+    "jjs_debug_point_flags_dev": [_P, _Z, _P, _P],
+    "jjs_debug_comb_table_bytes": [],
+    "jjs_debug_comb_table": [_I, _P],
+}
+_RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
+
+
+class JjsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JjsError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI and the header diverge
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, _I)
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().jjs_last_error()
+        raise JjsError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,299 @@
+"""Host-side interface over libjjs_gpu.so.
+
+Two levels:
+
+* `Engine`: batch calls on torch CUDA tensors (resident data; asynchronous on torch's current
+  stream) or numpy arrays (host buffers; blocking).  Arrays are uint8, SoA: scalars / field
+  elements (n, 32) little-endian canonical; points (n, 64) = affine u || v.
+* `PublicKey` / `Signature` & co.: the reference crate's types and method names
+  (`PublicKey::verify(&self, &Signature, BlsScalar) -> Result<(), Error>`, reference
+  src/keys/public.rs:114; `PublicKeyDouble::verify` src/keys/public/double.rs:86;
+  `PublicKeyVarGen::verify` src/keys/public/var_gen.rs:107) plus the batch entry point a shim would
+  add (`verify_batch`).  Errors mirror reference src/error.rs:13-19.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Sequence
+
+import numpy as np
+
+from . import _ffi
+
+STATUS_NAMES = ("Ok", "InvalidPoint", "InvalidSignature", "Malformed")
+
+
+class Error(Exception):
+    """Base of the reference's `Error` enum variants reachable from verify."""
+
+
+class InvalidPoint(Error):
+    def __str__(self):
+        return "Invalid Point"
+
+
+class InvalidSignature(Error):
+    def __str__(self):
+        return "Invalid Signature"
+
+
+class Malformed(Error):
+    """Non-canonical encoding; unreachable through the Rust types (their from_bytes rejects it)."""
+
+    def __str__(self):
+        return "Malformed encoding"
+
+
+_ERRORS = {1: InvalidPoint, 2: InvalidSignature, 3: Malformed}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class Engine:
+    """One engine per process, bound to the current HIP device (one process per GPU)."""
+
+    def __init__(self):
+        self._lib = _ffi.lib()
+        _ffi.check(self._lib.jjs_init(0), "jjs_init")
+
+    # ---- helpers ------------------------------------------------------------------------------
+    @staticmethod
+    def _dev_ptr(t, width, n=None):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+            raise ValueError("expected a contiguous uint8 CUDA tensor")
+        if t.dim() != 2 or t.shape[1] != width or (n is not None and t.shape[0] != n):
+            raise ValueError(f"expected shape (n, {width}), got {tuple(t.shape)}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _host(a, width):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        if a.ndim != 2 or a.shape[1] != width:
+            raise ValueError(f"expected shape (n, {width}), got {a.shape}")
+        return a
+
+    _WIDTHS = {"single": (32, 64, 64, 32), "double": (32, 64, 64, 64, 64, 32), "vargen": (32, 64, 64, 64, 32)}
+
+    def verify(self, scheme: str, *arrays, want_status: bool = True):
+        """Batch verify.  Argument order per scheme: single (u, R, PK, m); double (u, R, R', PK, PK', m);
+        vargen (u, R, PK, Gen, m).  Returns (status, tally): same kind as the inputs (torch CUDA
+        tensors, asynchronous on the current stream, or numpy arrays, blocking)."""
+        widths = self._WIDTHS[scheme]
+        if len(arrays) != len(widths):
+            raise ValueError(f"{scheme} verify takes {len(widths)} arrays")
+        if _is_torch(arrays[0]):
+            import torch
+            n = arrays[0].shape[0]
+            ptrs = [self._dev_ptr(a, w, n) for a, w in zip(arrays, widths)]
+            dev = arrays[0].device
+            status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)[:n] if want_status else None
+            tally = torch.zeros(4, dtype=torch.int64, device=dev)
+            fn = getattr(self._lib, f"jjs_verify_{scheme}_dev")
+            _ffi.check(fn(*ptrs, n, ctypes.c_void_p(status.data_ptr()) if want_status and n else None,
+                          ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}_dev")
+            return status, tally
+        host = [self._host(a, w) for a, w in zip(arrays, widths)]
+        n = host[0].shape[0]
+        if any(h.shape[0] != n for h in host):
+            raise ValueError("all arrays must have the same number of items")
+        status = np.empty(n, np.uint8)
+        tally = np.zeros(4, np.uint64)
+        fn = getattr(self._lib, f"jjs_verify_{scheme}")
+        _ffi.check(fn(*[h.ctypes.data_as(ctypes.c_void_p) for h in host], n, status.ctypes.data_as(ctypes.c_void_p),
+                      tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}")
+        return status, tally
+
+    def challenge(self, scheme: str, *arrays):
+        """250-bit challenge per item (torch CUDA tensors): single (R, PK, m); double (R, R', PK, PK', m);
+        vargen (R, PK, Gen, m)."""
+        import torch
+        widths = self._WIDTHS[scheme][1:]
+        n = arrays[0].shape[0]
+        ptrs = [self._dev_ptr(a, w, n) for a, w in zip(arrays, widths)]
+        out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=arrays[0].device)[:n]
+        fn = getattr(self._lib, f"jjs_challenge_{scheme}_dev")
+        _ffi.check(fn(*ptrs, n, ctypes.c_void_p(out.data_ptr()), self._stream()), f"jjs_challenge_{scheme}_dev")
+        return out
+
+    def sign(self, scheme: str, sk, rnd, m, gen_scalar=None):
+        """Synthetic-input generator (NOT constant time).  torch CUDA tensors in and out.
+        single -> (u, R, PK); double -> (u, R, R', PK, PK'); vargen -> (u, R, PK, Gen)."""
+        import torch
+        n = sk.shape[0]
+        dev = sk.device
+        p = lambda t, w=32: self._dev_ptr(t, w, n)  # noqa: E731
+        new = lambda w: torch.empty((max(n, 1), w), dtype=torch.uint8, device=dev)[:n]  # noqa: E731
+        o = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        u = new(32)
+        if scheme == "single":
+            R, PK = new(64), new(64)
+            _ffi.check(self._lib.jjs_sign_single_dev(p(sk), p(rnd), p(m), n, o(u), o(R), o(PK), self._stream()), "jjs_sign_single_dev")
+            return u, R, PK
+        if scheme == "double":
+            R, Rp, PK, PKp = new(64), new(64), new(64), new(64)
+            _ffi.check(self._lib.jjs_sign_double_dev(p(sk), p(rnd), p(m), n, o(u), o(R), o(Rp), o(PK), o(PKp), self._stream()),
+                       "jjs_sign_double_dev")
+            return u, R, Rp, PK, PKp
+        if scheme == "vargen":
+            R, PK, Gen = new(64), new(64), new(64)
+            _ffi.check(self._lib.jjs_sign_vargen_dev(p(sk), p(gen_scalar), p(rnd), p(m), n, o(u), o(R), o(PK), o(Gen), self._stream()),
+                       "jjs_sign_vargen_dev")
+            return u, R, PK, Gen
+        raise ValueError(scheme)
+
+    # ---- primitives for parity tests ------------------------------------------------------------
+    def debug_fq_mul(self, a, b):
+        import torch
+        n = a.shape[0]
+        out = torch.empty_like(a)
+        _ffi.check(self._lib.jjs_debug_fq_mul_dev(self._dev_ptr(a, 32, n), self._dev_ptr(b, 32, n), n,
+                                                  ctypes.c_void_p(out.data_ptr()), self._stream()), "jjs_debug_fq_mul_dev")
+        return out
+
+    def debug_poseidon(self, x):
+        import torch
+        n, k, w = x.shape
+        assert w == 32 and x.is_contiguous()
+        out = torch.empty((n, 32), dtype=torch.uint8, device=x.device)
+        _ffi.check(self._lib.jjs_debug_poseidon_dev(ctypes.c_void_p(x.data_ptr()), k, n, ctypes.c_void_p(out.data_ptr()),
+                                                    self._stream()), "jjs_debug_poseidon_dev")
+        return out
+
+    def debug_point_flags(self, pts):
+        import torch
+        n = pts.shape[0]
+        out = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        _ffi.check(self._lib.jjs_debug_point_flags_dev(self._dev_ptr(pts, 64, n), n, ctypes.c_void_p(out.data_ptr()),
+                                                       self._stream()), "jjs_debug_point_flags_dev")
+        return out
+
+    def debug_comb_table(self, which: int) -> np.ndarray:
+        nbytes = self._lib.jjs_debug_comb_table_bytes()
+        out = np.empty(nbytes // 4, np.uint32)
+        _ffi.check(self._lib.jjs_debug_comb_table(which, out.ctypes.data_as(ctypes.c_void_p)), "jjs_debug_comb_table")
+        return out.reshape(32, 256, 28)
+
+    def sync(self):
+        _ffi.check(self._lib.jjs_stream_sync(self._stream()), "jjs_stream_sync")
+
+
+_engine = None
+
+
+def engine() -> Engine:
+    global _engine
+    if _engine is None:
+        _engine = Engine()
+    return _engine
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-shaped types: affine points as 64 bytes, scalars as 32 bytes
+# ------------------------------------------------------------------------------------------------
+def _b(x, n):
+    x = bytes(x)
+    if len(x) != n:
+        raise ValueError(f"expected {n} bytes, got {len(x)}")
+    return x
+
+
+@dataclass(frozen=True)
+class Signature:
+    """`Signature { u, R }` (reference src/signatures.rs:62-65); R as affine u || v."""
+    u: bytes
+    R: bytes
+
+
+@dataclass(frozen=True)
+class SignatureDouble:
+    """`SignatureDouble { u, R, R_prime }` (reference src/signatures/double.rs:66-70)."""
+    u: bytes
+    R: bytes
+    R_prime: bytes
+
+
+@dataclass(frozen=True)
+class SignatureVarGen:
+    """`SignatureVarGen { u, R }` (reference src/signatures/var_gen.rs)."""
+    u: bytes
+    R: bytes
+
+
+def _rows(items, width):
+    return np.frombuffer(b"".join(_b(x, width) for x in items), np.uint8).reshape(len(items), width)
+
+
+def _raise_first(status):
+    for s in status:
+        if s:
+            raise _ERRORS[int(s)]()
+
+
+@dataclass(frozen=True)
+class PublicKey:
+    """`PublicKey(JubJubExtended)` (reference src/keys/public.rs:52); the point as affine u || v."""
+    point: bytes
+
+    def verify(self, sig: Signature, message: bytes) -> None:
+        """`PublicKey::verify` (reference src/keys/public.rs:114-135): returns None or raises."""
+        _raise_first(self.verify_batch([(self, sig, message)]))
+
+    @staticmethod
+    def verify_batch(items: Sequence[tuple]) -> np.ndarray:
+        """items: (PublicKey, Signature, message bytes).  Returns the status byte per item."""
+        if not items:
+            return np.zeros(0, np.uint8)
+        st, _ = engine().verify("single", _rows([s.u for _, s, _ in items], 32), _rows([s.R for _, s, _ in items], 64),
+                                _rows([k.point for k, _, _ in items], 64), _rows([m for _, _, m in items], 32))
+        return st
+
+
+@dataclass(frozen=True)
+class PublicKeyDouble:
+    """`PublicKeyDouble(pk, pk_prime)` (reference src/keys/public/double.rs:45)."""
+    pk: bytes
+    pk_prime: bytes
+
+    def verify(self, sig: SignatureDouble, message: bytes) -> None:
+        """`PublicKeyDouble::verify` (reference src/keys/public/double.rs:86-117)."""
+        _raise_first(self.verify_batch([(self, sig, message)]))
+
+    @staticmethod
+    def verify_batch(items: Sequence[tuple]) -> np.ndarray:
+        if not items:
+            return np.zeros(0, np.uint8)
+        st, _ = engine().verify(
+            "double", _rows([s.u for _, s, _ in items], 32), _rows([s.R for _, s, _ in items], 64),
+            _rows([s.R_prime for _, s, _ in items], 64), _rows([k.pk for k, _, _ in items], 64),
+            _rows([k.pk_prime for k, _, _ in items], 64), _rows([m for _, _, m in items], 32))
+        return st
+
+
+@dataclass(frozen=True)
+class PublicKeyVarGen:
+    """`PublicKeyVarGen { pk, generator }` (reference src/keys/public/var_gen.rs:40-43)."""
+    pk: bytes
+    generator: bytes
+
+    def verify(self, sig: SignatureVarGen, message: bytes) -> None:
+        """`PublicKeyVarGen::verify` (reference src/keys/public/var_gen.rs:107-133)."""
+        _raise_first(self.verify_batch([(self, sig, message)]))
+
+    @staticmethod
+    def verify_batch(items: Sequence[tuple]) -> np.ndarray:
+        if not items:
+            return np.zeros(0, np.uint8)
+        st, _ = engine().verify(
+            "vargen", _rows([s.u for _, s, _ in items], 32), _rows([s.R for _, s, _ in items], 64),
+            _rows([k.pk for k, _, _ in items], 64), _rows([k.generator for k, _, _ in items], 64),
+            _rows([m for _, _, m in items], 32))
+        return st

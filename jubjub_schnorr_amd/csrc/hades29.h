@@ -35,8 +35,13 @@ JJS_HD void hades_permute(hades_state& st) {
             for (int i = 0; i < 4; ++i) t[i] = fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i])));
         }
         t[4] = fq_as<1, 3>(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_RC[5 * rnd + 4]))));
-#pragma unroll
-        for (int i = 0; i < 5; ++i) st.s[i] = fq_dot_const<5, 3>(JJS_MDS[i], t);
+        // One copy of the dot-product code: rows are produced in order into s[4] while the
+        // state registers rotate down, so after five steps s[i] holds row i (static indices only).
+#pragma unroll 1
+        for (int i = 0; i < 5; ++i) {
+            fe_n row = fq_dot_const<5, 3>(JJS_MDS[i], t);
+            st.s[0] = st.s[1]; st.s[1] = st.s[2]; st.s[2] = st.s[3]; st.s[3] = st.s[4]; st.s[4] = row;
+        }
     }
 }
 

@@ -1,0 +1,444 @@
+// libjjs_gpu.so: HIP kernels (gfx950) + the C ABI of include/jjs_gpu.h.
+//
+// One signature per lane.  A launch is one persistent pass: the grid is sized to what the chip
+// can hold resident (256 CUs x blocks/CU from the occupancy query), each lane strides over the
+// batch, and each lane owns WS_WORDS_PER_LANE words of workspace for its window tables.  The
+// per-status tally is reduced with wave ballots and one atomic per wave per status.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/jjs_gpu.h"
+#include "schemes.h"
+#include "sign_core.h"
+
+using namespace jjs;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+__global__ __launch_bounds__(BLOCK) void verify_kernel(verify_params P) {
+    const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    uint32_t* ws = P.workspace + gtid * WS_WORDS_PER_LANE;
+    for (uint64_t base = 0; base < P.n; base += total) {
+        const uint64_t item = base + gtid;
+        const bool active = item < P.n;
+        const uint64_t it = active ? item : P.n - 1;
+        const uint32_t st = verify_item(P, it, ws, active);
+        if (active && P.status) P.status[item] = (uint8_t)st;
+        if (P.tally) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                unsigned long long b = __ballot(active && st == k);
+                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
+            }
+        }
+    }
+}
+
+struct challenge_params {
+    uint32_t n_hash, pad_;
+    fe_src hash_in[10];
+    uint64_t n;
+    uint8_t* c_out;
+};
+__global__ __launch_bounds__(BLOCK) void challenge_kernel(challenge_params P) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total) {
+        fe_n d = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
+        store_words(P.c_out, item, truncate250(d));
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void sign_kernel(sign_params P) {
+    const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    uint32_t* ws = P.workspace + gtid * WS_WORDS_PER_LANE;
+    for (uint64_t item = gtid; item < P.n; item += total) sign_item(P, item, ws);
+}
+
+__global__ __launch_bounds__(BLOCK) void comb_kernel(uint32_t* table, int which) {
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= COMB_WINDOWS * COMB_ENTRIES) return;
+    build_comb_entry(table, which ? JJS_GN : JJS_G, t / COMB_ENTRIES, t % COMB_ENTRIES);
+}
+
+__global__ __launch_bounds__(BLOCK) void dbg_fq_mul_kernel(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe_src sa{a, 32, 0}, sb{b, 32, 0};
+    store_words(out, i, fq_to_words(fq_mul(load_fq(sa, i), load_fq(sb, i))));
+}
+__global__ __launch_bounds__(BLOCK) void dbg_poseidon_kernel(const uint8_t* in, uint32_t k, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe_src s{in, 32 * k, 0};
+    fe_n d = poseidon_digest((int)k, [&](int e) { return load_fq(s, i, 32u * (uint32_t)e); });
+    store_words(out, i, fq_to_words(d));
+}
+__global__ __launch_bounds__(BLOCK) void dbg_point_flags_kernel(const uint8_t* pts, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe_src s{pts, 64, 0};
+    fe_n u = load_fq(s, i), v = load_fq(s, i, 32);
+    out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | (is_torsion_free(u, v) ? 2 : 0) | (affine_is_identity(u, v) ? 4 : 0));
+}
+
+// ---------------------------------------------------------------------------------------------
+struct engine {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t* comb_g = nullptr;
+    uint32_t* comb_gn = nullptr;
+    uint8_t* tag = nullptr;
+    uint32_t* workspace = nullptr;
+    unsigned long long* tally = nullptr;
+    int grid_verify = 0, grid_sign = 0;
+    size_t ws_lanes = 0;
+    std::mutex mu;
+    char err[512] = "";
+};
+engine g;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g.err, sizeof(g.err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(x)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) return fail(JJS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int grid_for(int resident, size_t n) {
+    size_t want = (n + BLOCK - 1) / BLOCK;
+    if (want < 1) want = 1;
+    return (int)(want < (size_t)resident ? want : (size_t)resident);
+}
+
+int launch_verify(verify_params P, hipStream_t s) {
+    if (P.n == 0) return JJS_OK;
+    hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g.grid_verify, P.n)), dim3(BLOCK), 0, s, P);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+
+int check_ready() { return g.ready ? JJS_OK : fail(JJS_ERR_NOT_INIT, "jjs_init has not been called"); }
+
+template <typename... Ptrs>
+bool all_ok(Ptrs... p) {
+    return ((p != nullptr && aligned16(p)) && ...);
+}
+
+int verify_dev_common(verify_params P, void* status, void* tally, hipStream_t s) {
+    if (status && !aligned16(status)) return fail(JJS_ERR_ARG, "status must be 16-byte aligned");
+    if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
+    return launch_verify(P, s);
+}
+
+// host-buffer wrapper: stage inputs, run, copy back
+struct staged {
+    void* d = nullptr;
+    ~staged() { if (d) (void)hipFree(d); }
+    int up(const void* h, size_t bytes, hipStream_t s) {
+        HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+        if (bytes) HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+        return JJS_OK;
+    }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&d, bytes ? bytes : 16)); return JJS_OK; }
+};
+
+int finish_host(staged& st, uint8_t* status, uint64_t tally[4], size_t n) {
+    if (status && n) HIP_TRY(hipMemcpyAsync(status, st.d, n, hipMemcpyDeviceToHost, g.stream));
+    unsigned long long t[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(t, g.tally, sizeof(t), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return JJS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jjs_abi_version(void) { return 1; }
+const char* jjs_last_error(void) { return g.err; }
+
+int jjs_init(int device_count) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (device_count != 0 && device_count != 1)
+        return fail(JJS_ERR_ARG, "this version drives one device per process (got device_count=%d)", device_count);
+    if (g.ready) return JJS_OK;
+    HIP_TRY(hipGetDevice(&g.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    int per_cu_v = 0, per_cu_s = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
+    if (per_cu_v < 1) per_cu_v = 1;
+    if (per_cu_s < 1) per_cu_s = 1;
+    g.grid_verify = prop.multiProcessorCount * per_cu_v;
+    g.grid_sign = prop.multiProcessorCount * per_cu_s;
+    int lanes_blocks = g.grid_verify > g.grid_sign ? g.grid_verify : g.grid_sign;
+    g.ws_lanes = (size_t)lanes_blocks * BLOCK;
+    HIP_TRY(hipMalloc(&g.workspace, g.ws_lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&g.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&g.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&g.tag, 32));
+    HIP_TRY(hipMalloc(&g.tally, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(g.tag, JJS_DOUBLE_TAG_WORDS, 32, hipMemcpyHostToDevice, g.stream));
+    const int blocks = (COMB_WINDOWS * COMB_ENTRIES + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, g.stream, g.comb_g, 0);
+    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, g.stream, g.comb_gn, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.ready = true;
+    return JJS_OK;
+}
+
+void jjs_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (!g.ready) return;
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(g.workspace); (void)hipFree(g.comb_g); (void)hipFree(g.comb_gn); (void)hipFree(g.tag); (void)hipFree(g.tally);
+    (void)hipStreamDestroy(g.stream);
+    g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
+    g.ready = false;
+}
+
+int jjs_stream_sync(void* stream) {
+    if (int rc = check_ready()) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return JJS_OK;
+}
+
+// ---- device-buffer entry points --------------------------------------------------------------
+int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
+                          void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
+                                           g.comb_g, o), status, tally, s);
+}
+int jjs_verify_double_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                          size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
+                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g.tag, g.comb_g, g.comb_gn, o),
+                             status, tally, s);
+}
+int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                          void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
+                                           (const uint8_t*)m, n, o), status, tally, s);
+}
+
+// ---- host-buffer entry points ----------------------------------------------------------------
+int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                      uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && (!u || !R || !PK || !m)) return fail(JJS_ERR_ARG, "null input pointer");
+    staged du, dR, dPK, dm, dst;
+    int rc;
+    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dPK.up(PK, 64 * n, g.stream)) ||
+        (rc = dm.up(m, 32 * n, g.stream)) || (rc = dst.alloc(n)))
+        return rc;
+    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
+    if ((rc = verify_dev_common(params_single((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dPK.d, (uint8_t*)dm.d, n, g.comb_g, o),
+                                dst.d, g.tally, g.stream)))
+        return rc;
+    return finish_host(dst, status, tally, n);
+}
+int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                      const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && (!u || !R || !Rp || !PK || !PKp || !m)) return fail(JJS_ERR_ARG, "null input pointer");
+    staged du, dR, dRp, dPK, dPKp, dm, dst;
+    int rc;
+    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dRp.up(Rp, 64 * n, g.stream)) ||
+        (rc = dPK.up(PK, 64 * n, g.stream)) || (rc = dPKp.up(PKp, 64 * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) ||
+        (rc = dst.alloc(n)))
+        return rc;
+    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
+    if ((rc = verify_dev_common(params_double((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dRp.d, (uint8_t*)dPK.d,
+                                              (uint8_t*)dPKp.d, (uint8_t*)dm.d, n, g.tag, g.comb_g, g.comb_gn, o),
+                                dst.d, g.tally, g.stream)))
+        return rc;
+    return finish_host(dst, status, tally, n);
+}
+int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                      size_t n, uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && (!u || !R || !PK || !Gen || !m)) return fail(JJS_ERR_ARG, "null input pointer");
+    staged du, dR, dPK, dG, dm, dst;
+    int rc;
+    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dPK.up(PK, 64 * n, g.stream)) ||
+        (rc = dG.up(Gen, 64 * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) || (rc = dst.alloc(n)))
+        return rc;
+    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
+    if ((rc = verify_dev_common(params_vargen((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dPK.d, (uint8_t*)dG.d,
+                                              (uint8_t*)dm.d, n, o), dst.d, g.tally, g.stream)))
+        return rc;
+    return finish_host(dst, status, tally, n);
+}
+
+// ---- challenge export ---------------------------------------------------------------------------
+static int launch_challenge(challenge_params P, void* stream) {
+    if (P.n == 0) return JJS_OK;
+    if (!P.c_out || !aligned16(P.c_out)) return fail(JJS_ERR_ARG, "c_out null or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    size_t blocks = (P.n + BLOCK - 1) / BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(challenge_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, P);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_t n, void* c_out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    verify_params V = params_single((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n, nullptr, out_ptrs{});
+    challenge_params P{};
+    P.n_hash = V.n_hash; P.n = n; P.c_out = (uint8_t*)c_out;
+    for (uint32_t i = 0; i < V.n_hash; ++i) P.hash_in[i] = V.hash_in[i];
+    return launch_challenge(P, stream);
+}
+int jjs_challenge_double_dev(const void* R, const void* Rp, const void* PK, const void* PKp, const void* m, size_t n,
+                             void* c_out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    verify_params V = params_double((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
+                                    (const uint8_t*)PKp, (const uint8_t*)m, n, g.tag, nullptr, nullptr, out_ptrs{});
+    challenge_params P{};
+    P.n_hash = V.n_hash; P.n = n; P.c_out = (uint8_t*)c_out;
+    for (uint32_t i = 0; i < V.n_hash; ++i) P.hash_in[i] = V.hash_in[i];
+    return launch_challenge(P, stream);
+}
+int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* c_out,
+                             void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    verify_params V = params_vargen((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
+                                    (const uint8_t*)m, n, out_ptrs{});
+    challenge_params P{};
+    P.n_hash = V.n_hash; P.n = n; P.c_out = (uint8_t*)c_out;
+    for (uint32_t i = 0; i < V.n_hash; ++i) P.hash_in[i] = V.hash_in[i];
+    return launch_challenge(P, stream);
+}
+
+// ---- signing (input generator) ------------------------------------------------------------------
+static int launch_sign(sign_params P, void* stream) {
+    if (P.n == 0) return JJS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    P.comb_g = g.comb_g; P.comb_gn = g.comb_gn; P.workspace = g.workspace;
+    hipLaunchKernelGGL(sign_kernel, dim3(grid_for(g.grid_sign, P.n)), dim3(BLOCK), 0, s, P);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int jjs_sign_single_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out, void* PK_out,
+                        void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sk, rnd, m, u_out, R_out, PK_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    sign_params P{};
+    P.scheme = SCHEME_SINGLE; P.sk = (const uint8_t*)sk; P.rnd = (const uint8_t*)rnd; P.m = (const uint8_t*)m; P.n = n;
+    P.u_out = (uint8_t*)u_out; P.R_out = (uint8_t*)R_out; P.PK_out = (uint8_t*)PK_out;
+    return launch_sign(P, stream);
+}
+int jjs_sign_double_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out, void* Rp_out,
+                        void* PK_out, void* PKp_out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sk, rnd, m, u_out, R_out, Rp_out, PK_out, PKp_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    sign_params P{};
+    P.scheme = SCHEME_DOUBLE; P.sk = (const uint8_t*)sk; P.rnd = (const uint8_t*)rnd; P.m = (const uint8_t*)m; P.n = n;
+    P.u_out = (uint8_t*)u_out; P.R_out = (uint8_t*)R_out; P.Rp_out = (uint8_t*)Rp_out; P.PK_out = (uint8_t*)PK_out;
+    P.PKp_out = (uint8_t*)PKp_out;
+    return launch_sign(P, stream);
+}
+int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd, const void* m, size_t n, void* u_out,
+                        void* R_out, void* PK_out, void* Gen_out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sk, gen_scalar, rnd, m, u_out, R_out, PK_out, Gen_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    sign_params P{};
+    P.scheme = SCHEME_VARGEN; P.sk = (const uint8_t*)sk; P.gen_scalar = (const uint8_t*)gen_scalar;
+    P.rnd = (const uint8_t*)rnd; P.m = (const uint8_t*)m; P.n = n;
+    P.u_out = (uint8_t*)u_out; P.R_out = (uint8_t*)R_out; P.PK_out = (uint8_t*)PK_out; P.Gen_out = (uint8_t*)Gen_out;
+    return launch_sign(P, stream);
+}
+
+// ---- debug primitives ------------------------------------------------------------------------------
+int jjs_debug_fq_mul_dev(const void* a, const void* b, size_t n, void* out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!all_ok(a, b, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dbg_fq_mul_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       (const uint8_t*)a, (const uint8_t*)b, (uint64_t)n, (uint8_t*)out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (k < 1 || k > JJS_MAX_HASH_INPUTS) return fail(JJS_ERR_ARG, "k out of range");
+    if (n == 0) return JJS_OK;
+    if (!all_ok(in, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dbg_poseidon_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       (const uint8_t*)in, (uint32_t)k, (uint64_t)n, (uint8_t*)out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!points || !aligned16(points) || !out) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dbg_point_flags_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       (const uint8_t*)points, (uint64_t)n, (uint8_t*)out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+size_t jjs_debug_comb_table_bytes(void) { return COMB_TABLE_WORDS * sizeof(uint32_t); }
+int jjs_debug_comb_table(int which, void* host_out) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (!host_out) return fail(JJS_ERR_ARG, "null pointer");
+    HIP_TRY(hipMemcpy(host_out, which ? g.comb_gn : g.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return JJS_OK;
+}
+
+}  // extern "C"

@@ -126,7 +126,15 @@ JJS_HD words8 recode_signed4(const words8& s) {
     }
     return r;
 }
-JJS_HD uint32_t nibble(const words8& s, int i) { return (s.w[i >> 3] >> ((i & 7) * 4)) & 15u; }
+// word j of s for a wave-uniform j, as a select chain (a dynamically indexed register array
+// would be demoted to scratch / LDS)
+JJS_HD uint32_t word_at(const words8& s, int j) {
+    uint32_t r = s.w[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = (j == k) ? s.w[k] : r;
+    return r;
+}
+JJS_HD uint32_t nibble(const words8& s, int i) { return (word_at(s, i >> 3) >> ((i & 7) * 4)) & 15u; }
 JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& sc, int w, bool need_t) {
     uint32_t nib = nibble(sc, w);
     int d = (w == 63) ? (int)nib : (int)nib - 8;
@@ -189,7 +197,7 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
     }
     if (!varbase) {
         for (int i = 0; i < COMB_WINDOWS; ++i) {
-            uint32_t byte = (u.w[i >> 2] >> ((i & 3) * 8)) & 255u;
+            uint32_t byte = (word_at(u, i >> 2) >> ((i & 3) * 8)) & 255u;
             const u32x4* p = reinterpret_cast<const u32x4*>(E.comb + ((size_t)i * COMB_ENTRIES + byte) * COMB_ENTRY_WORDS);
             uint32_t w[COMB_ENTRY_WORDS];
 #pragma unroll
@@ -205,7 +213,7 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
 }
 
 // one signature; ws = this lane's WS_WORDS_PER_LANE workspace words
-JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws) {
+JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws, bool write_c = true) {
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
     bool malformed = !words_lt(u, JJS_FR_WORDS);
@@ -221,7 +229,7 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws)
     // 3. challenge
     fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
     const words8 c = truncate250(digest);
-    if (P.c_out) store_words(P.c_out, item, c);
+    if (P.c_out && write_c) store_words(P.c_out, item, c);
 
     // 4. equations
     bool eq_ok = true;
