@@ -113,7 +113,8 @@ int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd,
 int jjs_debug_fq_mul_dev(const void* a, const void* b, size_t n, void* out, void* stream);
 /* out[i] = untruncated Poseidon digest of the k field elements at in[(i*k + j)*32] */
 int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* stream);
-/* out[i] bit0 = on curve, bit1 = torsion free, bit2 = identity */
+/* out[i] bit0 = on curve, bit1 = torsion free (pairing test, as used by verify; identity counts as
+ * torsion free), bit2 = identity, bit3 = torsion free by the reference's definition [r]P == O */
 int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream);
 /* copies the fixed-base table of G (which = 0) or G' (which = 1) to host memory; size in bytes via
  * jjs_debug_comb_table_bytes() */

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(BLOCK) void dbg_point_flags_kernel(const uint8_t* p
     if (i >= n) return;
     fe_src s{pts, 64, 0};
     fe_n u = load_fq(s, i), v = load_fq(s, i, 32);
-    out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | (is_torsion_free(u, v) ? 2 : 0) | (affine_is_identity(u, v) ? 4 : 0));
+    bool id = affine_is_identity(u, v);
+    out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | ((id || is_torsion_free(u, v)) ? 2 : 0) | (id ? 4 : 0) |
+                       (is_torsion_free_by_order(u, v) ? 8 : 0));
 }
 
 // ---------------------------------------------------------------------------------------------

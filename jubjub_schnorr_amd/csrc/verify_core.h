@@ -17,7 +17,7 @@
 //     workspace (144 B per entry, one lane's table contiguous); 252 shared doublings.
 //   * u*G (and u*G'): 8-bit fixed-base comb, 32 mixed additions from a 917 KB table (L2-resident).
 //   * var-gen: u*Gen joins the same window loop with a second per-lane table (Straus).
-//   * subgroup check: [r]P with the public bit pattern of r (wave-uniform control flow).
+//   * subgroup check: order-8 Tate pairing residue test, one exponentiation per point instead of [r]P.
 #pragma once
 #include "ed29.h"
 #include "hades29.h"
@@ -143,8 +143,10 @@ JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& s
     return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg, need_t);
 }
 
-// [r]P == identity for affine P, double-and-add over the public bits of r (top bit 251)
-JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
+// [r]P == identity for affine P, double-and-add over the public bits of r (top bit 251).
+// The reference's definition (dusk-jubjub `is_torsion_free`); kept as the cross-check of the
+// pairing test below (tools/devcheck, debug entry point) -- the verify path uses the pairing test.
+JJS_HD bool is_torsion_free_by_order(const fe_n& u, const fe_n& v) {
     ext_pt p = ext_from_affine(u, v);
     niels_pt n = to_niels(p);
     ext_pt acc = p;
@@ -154,6 +156,31 @@ JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
         if (bit) acc = ext_add_affine_niels(acc, n.ypx, n.ymx, n.t2d, false);
     }
     return ext_is_identity(acc);
+}
+
+// Same predicate for every ON-CURVE point other than the identity, at ~1/8 of the cost: P is in the
+// prime-order subgroup iff the reduced order-8 Tate pairing with the generator T8 of the (cyclic)
+// 2-Sylow subgroup is trivial: g(P)^((q-1)/8) == 1, with g the Miller function cleared of
+// denominators modulo 8th powers (derivation and constants: tools/gen_constants.py).  g vanishes on
+// the small-order points it cannot evaluate (including the identity), which yields "false"; the
+// caller rejects the identity separately, as the reference does.
+JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
+    auto opv = fq_add(fq_one(), v);                       // 1 + v          <2,3>
+    auto omv = fq_sub(fq_one(), v);                       // 1 - v          <3,4>
+    fe_n w = fq_mul(omv, u);                              // W = (1-v) u
+    fe_n x = fq_mul(opv, u);                              // X = (1+v) u
+    fe_n xw[2] = {x, w};
+    auto l1 = fq_norm(fq_add(opv, fq_dot_const<2, 2>(JJS_PAIR_L1, xw)));                       // <1,5>
+    auto l2 = fq_norm(fq_add(opv, fq_mul(x, fe_from_const<1, 1>(JJS_PAIR_NEG_L2))));          // <1,5>
+    auto vv = fq_norm(fq_sub(x, w));                                                           // <1,5>
+    fe_n a = fq_mul(fq_sqr(l1), l2);
+    a = fq_sqr(fq_mul(a, fq_sqr(vv)));                    // L1^4 L2^2 V^4
+    fe_n y = fq_mul(fq_mul(x, w), fe_from_const<1, 1>(JJS_PAIR_B));
+    fe_n y2 = fq_sqr(y);
+    fe_n y7 = fq_mul(fq_mul(fq_sqr(y2), y2), y);
+    fe_n g = fq_mul(a, y7);
+    fe_n e = fq_pow_public(g, JJS_PAIR_EXP_WORDS, 252);
+    return fq_eq(e, fq_one());
 }
 
 // is_torsion_free && is_on_curve && !is_identity  (src/keys/public.rs:159-164)

@@ -71,6 +71,131 @@ def sponge_tag(n_in, n_out=1, domain=0):
     return int.from_bytes(hashlib.blake2b(data, digest_size=64).digest(), "little") % Q
 
 
+# ---- optimised Hades: one constant and one sparse matrix per partial round ---------------------------
+# Partial round r:  x += c_r ; x[4] = x[4]^5 ; x = M x.   Two rewrites, both exact:
+#  (1) the constants on lanes 0..3 commute with the S-box, so M * (c_r with lane 4 zeroed) is pushed
+#      into c_{r+1}; only a scalar kappa_r on lane 4 remains per round and the last carry is folded into
+#      the constants of the first full round that follows;
+#  (2) with lane 4 first, M_k = [[a, w^T], [v, Mh]] = diag(1, Mh) * [[a, w^T], [Mh^-1 v, I]] = A_k B_k and
+#      A_k commutes with the next round's S-box, so round k applies only the sparse B_k and
+#      M_{k+1} = M * A_k; the last partial round applies the dense M_60.
+def mat_mul(a, b):
+    return [[sum(a[i][k] * b[k][j] for k in range(len(b))) % Q for j in range(len(b[0]))] for i in range(len(a))]
+
+
+def mat_vec(a, x):
+    return [sum(a[i][j] * x[j] for j in range(len(x))) % Q for i in range(len(a))]
+
+
+def mat_inv(a):
+    n = len(a)
+    m = [list(r) + [int(i == j) for j in range(n)] for i, r in enumerate(a)]
+    for c in range(n):
+        p = next(r for r in range(c, n) if m[r][c] % Q)
+        m[c], m[p] = m[p], m[c]
+        iv = inv(m[c][c])
+        m[c] = [x * iv % Q for x in m[c]]
+        for r in range(n):
+            if r != c and m[r][c]:
+                f = m[r][c]
+                m[r] = [(x - f * y) % Q for x, y in zip(m[r], m[c])]
+    return [r[n:] for r in m]
+
+
+def optimised_hades():
+    rc, m = round_constants(), mds()
+    half = N_FULL // 2
+    c = [rc[WIDTH * r:WIDTH * r + WIDTH] for r in range(N_ROUNDS)]
+    kappa, carry = [], [0] * WIDTH
+    for r in range(half, half + N_PARTIAL):
+        cr = [(x + y) % Q for x, y in zip(c[r], carry)]
+        kappa.append(cr[4])
+        carry = mat_vec(m, cr[:4] + [0])
+    full = [list(c[r]) for r in range(half)] + [list(c[r]) for r in range(half + N_PARTIAL, N_ROUNDS)]
+    full[half] = [(x + y) % Q for x, y in zip(full[half], carry)]
+    rows, cols, mk = [], [], m
+    for k in range(N_PARTIAL - 1):
+        mh = [r[:4] for r in mk[:4]]                      # lanes 0..3 x lanes 0..3
+        v = [mk[i][4] for i in range(4)]                  # lane 4 -> lanes 0..3
+        rows.append(list(mk[4]))                          # new lane 4 = <row, x>
+        cols.append(mat_vec(mat_inv(mh), v))              # lane i += col[i] * x[4]
+        ak = [mh[i] + [0] for i in range(4)] + [[0, 0, 0, 0, 1]]
+        mk = mat_mul(m, ak)
+    return kappa, full, rows, cols, mk
+
+
+def hades_reference(state):
+    rc, m = round_constants(), mds()
+    s = list(state)
+    for r in range(N_ROUNDS):
+        s = [(x + rc[WIDTH * r + i]) % Q for i, x in enumerate(s)]
+        if r < N_FULL // 2 or r >= N_FULL // 2 + N_PARTIAL:
+            s = [pow(x, 5, Q) for x in s]
+        else:
+            s[4] = pow(s[4], 5, Q)
+        s = mat_vec(m, s)
+    return s
+
+
+def hades_optimised(state, kappa, full, rows, cols, m_last):
+    m, s, half = mds(), list(state), N_FULL // 2
+    for r in range(half):
+        s = mat_vec(m, [pow((x + full[r][i]) % Q, 5, Q) for i, x in enumerate(s)])
+    for k in range(N_PARTIAL):
+        x4 = pow((s[4] + kappa[k]) % Q, 5, Q)
+        if k < N_PARTIAL - 1:
+            s = [(s[i] + cols[k][i] * x4) % Q for i in range(4)] + [(sum(rows[k][j] * s[j] for j in range(4)) + rows[k][4] * x4) % Q]
+        else:
+            s = mat_vec(m_last, s[:4] + [x4])
+    for r in range(half, N_FULL):
+        s = mat_vec(m, [pow((x + full[r][i]) % Q, 5, Q) for i, x in enumerate(s)])
+    return s
+
+
+# ---- subgroup test by the order-8 Tate pairing ---------------------------------------------------
+# JubJub's 2-Sylow subgroup is cyclic of order 8 (a = -1 is a square, d is not), generated by T8.
+# P is in the prime-order subgroup  <=>  the reduced Tate pairing t_8(T8, P) is trivial, i.e.
+#   f_{8,T8}(P)^((q-1)/8) == 1.
+# Through the birational map to the Montgomery model  B y^2 = x^3 + A x^2 + x,
+#   (u, v) -> (x, y) = ((1+v)/(1-v), (1+v)/((1-v) u)),
+# Miller's algorithm gives f_8 = l_T^4 * l_2T^2 / (v_2T^4 * x) / B   (B: normalisation at infinity),
+# where l_T, l_2T are the tangents at T8 and 2*T8 and v_2T = x - x(2*T8) = x - 1.  Clearing
+# denominators modulo 8th powers, with W = (1-v) u and X = (1+v) u:
+#   g = L1^4 * L2^2 * V^4 * (B * X * W)^7,   L1 = (1+v) - l1 X + c1 W,  L2 = (1+v) - l2 X,  V = X - W.
+# g vanishes exactly on the 8-torsion points in the support, for which the answer is "no" as well.
+T8 = (0x71D4DF38BA9E7973EAAAE086A16618D17AA41AC43DAE8582D92E6A7927200D43,
+      0x4958BDB21966982E16A13035AD4D72669106EE90F384A4A1FF0D2068EFF496DD)
+
+
+def ed_add(p1, p2):
+    (u1, v1), (u2, v2) = p1, p2
+    t = D * u1 * u2 % Q * v1 * v2 % Q
+    return ((u1 * v2 + v1 * u2) * inv(1 + t) % Q, (v1 * v2 + u1 * u2) * inv(1 - t) % Q)
+
+
+def pairing_constants():
+    t2 = ed_add(T8, T8)
+    t4 = ed_add(t2, t2)
+    assert t4 == (0, Q - 1) and ed_add(t4, t4) == (0, 1), "T8 must have exact order 8"
+    assert (T8[1] ** 2 - T8[0] ** 2 - 1 - D * T8[0] ** 2 * T8[1] ** 2) % Q == 0
+    a = Q - 1
+    A = 2 * (a + D) * inv(a - D) % Q
+    B = 4 * inv(a - D) % Q
+
+    def to_mont(p):
+        return ((1 + p[1]) * inv(1 - p[1]) % Q, (1 + p[1]) * inv((1 - p[1]) * p[0]) % Q)
+
+    def slope(pt):
+        return (3 * pt[0] ** 2 + 2 * A * pt[0] + 1) * inv(2 * B * pt[1]) % Q
+
+    m1, m2 = to_mont(T8), to_mont(t2)
+    l1, l2 = slope(m1), slope(m2)
+    assert (B * l1 * l1 - A - 2 * m1[0]) % Q == m2[0] == 1
+    c1, c2 = (l1 * m1[0] - m1[1]) % Q, (l2 * m2[0] - m2[1]) % Q
+    assert c2 == 0
+    return {"NEG_L1": (-l1) % Q, "C1": c1, "NEG_L2": (-l2) % Q, "B": B}
+
+
 def main():
     rc, m = round_constants(), mds()
     rr = (1 << 256) % R_ORDER
@@ -95,8 +220,34 @@ def main():
     for n in range(MAX_INPUTS + 1):
         L.append("  %s," % limbs29(mont(sponge_tag(n)) if n else 0))
     L.append("};")
+    pc = pairing_constants()
+    L.append("// subgroup test (order-8 Tate pairing): rows {-l1, c1} for L1, then -l2 and B")
+    L.append("JJS_CONST uint32_t JJS_PAIR_L1[2][9] = {%s, %s};" % (limbs29(mont(pc["NEG_L1"])), limbs29(mont(pc["C1"]))))
+    L.append("JJS_CONST uint32_t JJS_PAIR_NEG_L2[9] = %s;" % limbs29(mont(pc["NEG_L2"])))
+    L.append("JJS_CONST uint32_t JJS_PAIR_B[9] = %s;" % limbs29(mont(pc["B"])))
+    L.append("JJS_CONST uint32_t JJS_PAIR_EXP_WORDS[8] = %s;  // (q - 1) / 8" % words32((Q - 1) // 8))
     L.append("JJS_CONST uint32_t JJS_RC[%d][9] = {" % len(rc))
     L += ["  %s," % limbs29(mont(c)) for c in rc]
+    L.append("};")
+    kappa, full, rows, cols, m_last = optimised_hades()
+    for trial in range(3):
+        st = [int.from_bytes(hashlib.sha256(b"hades-selfcheck-%d-%d" % (trial, i)).digest(), "little") % Q for i in range(WIDTH)]
+        assert hades_reference(st) == hades_optimised(st, kappa, full, rows, cols, m_last), "optimised Hades differs"
+    L.append("// optimised Hades (see optimised_hades() in the generator)")
+    L.append("JJS_CONST uint32_t JJS_HF_RC[%d][5][9] = {" % N_FULL)
+    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in full]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HP_KAPPA[%d][9] = {" % N_PARTIAL)
+    L += ["  %s," % limbs29(mont(x)) for x in kappa]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HP_ROW[%d][5][9] = {" % (N_PARTIAL - 1))
+    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in rows]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HP_COL[%d][4][9] = {" % (N_PARTIAL - 1))
+    L += ["  {" + ", ".join(limbs29(mont(x)) for x in col) + "}," for col in cols]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HP_LAST[5][5][9] = {")
+    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in m_last]
     L.append("};")
     L.append("JJS_CONST uint32_t JJS_MDS[5][5][9] = {")
     for i in range(WIDTH):

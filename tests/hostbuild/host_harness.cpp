@@ -87,13 +87,15 @@ int jjs_host_poseidon(const uint8_t* in, size_t k, size_t n, uint8_t* out) {
     }
     return 0;
 }
-// bit0 on_curve, bit1 torsion_free, bit2 identity
+// bit0 on_curve, bit1 torsion_free (pairing test), bit2 identity, bit3 torsion_free ([r]P == O)
 int jjs_host_point_flags(const uint8_t* P, size_t n, uint8_t* out) {
     for (size_t i = 0; i < n; ++i) {
         words8 x, y;
         memcpy(x.w, P + 64 * i, 32); memcpy(y.w, P + 64 * i + 32, 32);
         fe_n u = fq_from_words(x), v = fq_from_words(y);
-        out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | (is_torsion_free(u, v) ? 2 : 0) | (affine_is_identity(u, v) ? 4 : 0));
+        bool id = affine_is_identity(u, v);
+    out[i] = (uint8_t)((affine_on_curve(u, v) ? 1 : 0) | ((id || is_torsion_free(u, v)) ? 2 : 0) | (id ? 4 : 0) |
+                       (is_torsion_free_by_order(u, v) ? 8 : 0));
     }
     return 0;
 }

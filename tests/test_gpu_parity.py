@@ -68,8 +68,11 @@ def test_point_flags(eng):
     got, want = host(eng.debug_point_flags(dev(arr))), oc.point_flags(arr)
     # [r]P of an off-curve point depends on the formulas used; only on-curve points have a torsion bit
     off = (want & 1) == 0
+    by_order = (got >> 3) & 1
+    got &= 7
     got[off] &= 0b101; want[off] &= 0b101
-    assert (got == want).all()
+    assert (got == want).all()                              # pairing-based subgroup test
+    assert (by_order[~off] == ((want[~off] >> 1) & 1)).all()  # [r]P cross-check
     assert (want[:8] == [3, 1, 1, 1, 1, 1, 1, 1]).all()
 
 
