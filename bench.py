@@ -155,6 +155,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import jubjub_schnorr_amd as jjs
+    from jubjub_schnorr_amd.sharding import allreduce_tally
     eng = jjs.engine()
     scheme = args.scheme
     n = 1 << args.log2_items_per_gpu
@@ -164,8 +165,7 @@ def main():
 
     def step():
         st, tally = eng.verify(scheme, *call)
-        if dist is not None:
-            dist.all_reduce(tally)          # RCCL over xGMI: 4 x int64, the path's only exchange
+        allreduce_tally(tally)              # RCCL over xGMI: 4 x int64, the path's only exchange
         return st, tally
 
     def fence():
@@ -185,8 +185,7 @@ def main():
         e1.record()
         tally = tally_local
         if dist is not None:
-            tally = tally_local.clone()
-            dist.all_reduce(tally)
+            tally = allreduce_tally(tally_local.clone())
         evs.append((e0, e1))
     fence()
     elapsed = time.perf_counter() - t0
