@@ -20,74 +20,6 @@ struct sign_params {
     uint32_t* workspace;  // WS_WORDS_PER_LANE words per resident lane
 };
 
-// ---- arithmetic mod r (JubJubScalar), 8 x 32-bit Montgomery; only u = r - c*sk needs it ----------
-JJS_HD words8 fr_mont_mul(const words8& a, const words8& b) {
-    uint32_t t[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c += (uint64_t)a.w[j] * b.w[i] + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (uint32_t)c;
-        t[9] = (uint32_t)(c >> 32);
-        uint32_t mq = t[0] * JJS_FR_INV32;
-        c = (uint64_t)mq * JJS_FR_WORDS[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            c += (uint64_t)mq * JJS_FR_WORDS[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = t[9] + (uint32_t)(c >> 32);
-    }
-    words8 r, s;
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        r.w[i] = t[i];
-        uint64_t d = (uint64_t)t[i] - JJS_FR_WORDS[i] - borrow;
-        s.w[i] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
-    }
-    bool keep = (t[8] == 0) && borrow;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.w[i] = keep ? r.w[i] : s.w[i];
-    return r;
-}
-// (a - b*c) mod r for canonical a, b, c
-JJS_HD words8 fr_sub_mul(const words8& a, const words8& b, const words8& c) {
-    words8 r2;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
-    words8 bc = fr_mont_mul(fr_mont_mul(b, r2), c);
-    words8 d;
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t t = (uint64_t)a.w[i] - bc.w[i] - borrow;
-        d.w[i] = (uint32_t)t;
-        borrow = (uint32_t)(t >> 63);
-    }
-    uint32_t mask = 0u - borrow, carry = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t t = (uint64_t)d.w[i] + (JJS_FR_WORDS[i] & mask) + carry;
-        d.w[i] = (uint32_t)t;
-        carry = (uint32_t)(t >> 32);
-    }
-    return d;
-}
-
 // ---- scalar multiplications --------------------------------------------------------------------
 JJS_HD ext_pt comb_mul(const uint32_t* comb, const words8& k) {
     ext_pt acc = ext_identity();

@@ -13,10 +13,11 @@
 // kernel serves all three and nothing about a scheme is compiled in.
 //
 // Method (bit-exact in RESULT, not in method):
-//   * c*PK: signed 4-bit fixed windows over a per-lane table {0..8}*PK kept in a global-memory
-//     workspace (144 B per entry, one lane's table contiguous); 252 shared doublings.
-//   * u*G (and u*G'): 8-bit fixed-base comb, 32 mixed additions from a 917 KB table (L2-resident).
-//   * var-gen: u*Gen joins the same window loop with a second per-lane table (Straus).
+//   * fixed generator: half-size scalars (a = b*c mod r, |a|,|b| < 2^126 from a truncated Euclid) turn
+//     the equation into (b*u)*G + a*PK - b*R == O: 124 shared doublings, signed 4-bit windows over two
+//     per-lane tables {0..8}*PK, {0..8}*R in a global-memory workspace (144 B per entry), and an 8-bit
+//     fixed-base comb for G / G' (32 mixed additions from a 917 KB L2-resident table).
+//   * var-gen: u*Gen + c*PK by Straus over two per-lane tables, 252 shared doublings.
 //   * subgroup check: order-8 Tate pairing residue test, one exponentiation per point instead of [r]P.
 #pragma once
 #include "ed29.h"
@@ -135,12 +136,207 @@ JJS_HD uint32_t word_at(const words8& s, int j) {
     return r;
 }
 JJS_HD uint32_t nibble(const words8& s, int i) { return (word_at(s, i >> 3) >> ((i & 7) * 4)) & 15u; }
-JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& sc, int w, bool need_t) {
+// acc + (digit `w` of the recoded scalar) * P; `top` is the index of the unsigned top digit; `flip` adds
+// the opposite point (used for -b*R)
+JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& sc, int w, bool need_t, int top = 63,
+                         bool flip = false) {
     uint32_t nib = nibble(sc, w);
-    int d = (w == 63) ? (int)nib : (int)nib - 8;
+    int d = (w == top) ? (int)nib : (int)nib - 8;
     bool neg = d < 0;
     uint32_t idx = (uint32_t)(neg ? -d : d);
-    return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg, need_t);
+    return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg != flip, need_t);
+}
+
+// ---- arithmetic mod r (JubJubScalar), 8 x 32-bit Montgomery; only u = r - c*sk needs it ----------
+JJS_HD words8 fr_mont_mul(const words8& a, const words8& b) {
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c += (uint64_t)a.w[j] * b.w[i] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (uint32_t)c;
+        t[9] = (uint32_t)(c >> 32);
+        uint32_t mq = t[0] * JJS_FR_INV32;
+        c = (uint64_t)mq * JJS_FR_WORDS[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            c += (uint64_t)mq * JJS_FR_WORDS[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (uint32_t)c;
+        t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    words8 r, s;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r.w[i] = t[i];
+        uint64_t d = (uint64_t)t[i] - JJS_FR_WORDS[i] - borrow;
+        s.w[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+    }
+    bool keep = (t[8] == 0) && borrow;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.w[i] = keep ? r.w[i] : s.w[i];
+    return r;
+}
+// (a - b*c) mod r for canonical a, b, c
+JJS_HD words8 fr_sub_mul(const words8& a, const words8& b, const words8& c) {
+    words8 r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
+    words8 bc = fr_mont_mul(fr_mont_mul(b, r2), c);
+    words8 d;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.w[i] - bc.w[i] - borrow;
+        d.w[i] = (uint32_t)t;
+        borrow = (uint32_t)(t >> 63);
+    }
+    uint32_t mask = 0u - borrow, carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)d.w[i] + (JJS_FR_WORDS[i] & mask) + carry;
+        d.w[i] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+    return d;
+}
+
+// ---- half-size scalars (Antipa, Brown, Gallant, Lambert, Struik, Vanstone: "Accelerated verification
+// of ECDSA signatures") -------------------------------------------------------------------------------
+// For the challenge c find a, b with  a = b*c (mod r),  0 <= a < 2^126,  0 < |b| < 2^126, by running
+// Euclid on (r, c) until the remainder drops below 2^126.  Then, for points of order r,
+//     u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O      (b is invertible mod r),
+// which needs 126 shared doublings instead of 252.  The Euclid steps are taken one aligned
+// subtraction at a time (r0 -= r1 << k with r1 << k <= r0 < r1 << (k+1)), so every lane runs the same
+// loop body; lanes that have finished idle until the slowest lane of the wave is done.
+struct u128w {
+    uint32_t w[4];
+};
+struct half_scalars {
+    u128w a, b;      // a, |b| < 2^126
+    bool b_neg;
+};
+
+JJS_HD bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(x) != 0ull;
+#else
+    return x;
+#endif
+}
+JJS_HD int bitlen256(const words8& x) {
+    int bl = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bl = x.w[i] ? 32 * i + 32 - __builtin_clz(x.w[i]) : bl;
+    return bl;
+}
+// x << d for 0 <= d < 256, barrel shifter: word moves by 4, 2, 1 words, then a sub-word funnel shift
+template <int N>
+JJS_HD void shl_words(uint32_t (&x)[N], int d) {
+#pragma unroll
+    for (int stage = 4; stage >= 1; stage >>= 1) {
+        if (stage < N) {
+            bool on = (d & (32 * stage)) != 0;
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) x[i] = on ? (i >= stage ? x[i - stage] : 0u) : x[i];
+        }
+    }
+    int bs = d & 31;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        uint64_t v = ((uint64_t)x[i] << 32) | (i ? x[i - 1] : 0u);
+        x[i] = (uint32_t)((v << bs) >> 32);
+    }
+}
+template <int N>
+JJS_HD void shr1_words(uint32_t (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = (x[i] >> 1) | (i + 1 < N ? x[i + 1] << 31 : 0u);
+}
+template <int N>
+JJS_HD bool lt_words(const uint32_t (&a)[N], const uint32_t (&b)[N]) {  // a < b
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint64_t t = (uint64_t)a[i] - b[i] - borrow;
+        borrow = (uint32_t)(t >> 63);
+    }
+    return borrow != 0;
+}
+
+JJS_HD half_scalars half_size_scalars(const words8& c) {
+    uint32_t r0[8], r1[8], t0[4] = {0, 0, 0, 0}, t1[4] = {1, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r0[i] = JJS_FR_WORDS[i]; r1[i] = c.w[i]; }
+    bool neg = false;   // sign of t1; t0 always has the opposite sign (or is zero)
+    for (;;) {
+        words8 w1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w1.w[i] = r1[i];
+        const int bl1 = bitlen256(w1);
+        const bool active = bl1 > 126;
+        if (!wave_any(active)) break;
+        words8 w0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w0.w[i] = r0[i];
+        int d = bitlen256(w0) - bl1;
+        d = (active && d > 0) ? d : 0;
+        uint32_t x[8], y[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = r1[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = t1[i];
+        shl_words(x, d);
+        shl_words(y, d);
+        if (lt_words(r0, x)) { shr1_words(x); shr1_words(y); }   // only possible when d >= 1
+        uint32_t n0[8], m0[4];
+        uint32_t borrow = 0, carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t t = (uint64_t)r0[i] - x[i] - borrow;
+            n0[i] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint64_t t = (uint64_t)t0[i] + y[i] + carry;
+            m0[i] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        const bool swap = lt_words(n0, r1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t nr0 = swap ? r1[i] : n0[i], nr1 = swap ? n0[i] : r1[i];
+            r0[i] = active ? nr0 : r0[i];
+            r1[i] = active ? nr1 : r1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t nt0 = swap ? t1[i] : m0[i], nt1 = swap ? m0[i] : t1[i];
+            t0[i] = active ? nt0 : t0[i];
+            t1[i] = active ? nt1 : t1[i];
+        }
+        neg = (active && swap) ? !neg : neg;
+    }
+    half_scalars h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h.a.w[i] = r1[i]; h.b.w[i] = t1[i]; }
+    h.b_neg = neg;
+    return h;
 }
 
 // [r]P == identity for affine P, double-and-add over the public bits of r (top bit 251).
@@ -191,49 +387,109 @@ JJS_HD bool point_is_valid(const fe_n& u, const fe_n& v) {
     return tf && on && !id;
 }
 
-// u*Gen + c*PK == R
+JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
+    for (int i = 0; i < COMB_WINDOWS; ++i) {
+        uint32_t byte = (word_at(k, i >> 2) >> ((i & 3) * 8)) & 255u;
+        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + byte) * COMB_ENTRY_WORDS);
+        uint32_t w[COMB_ENTRY_WORDS];
+#pragma unroll
+        for (int k4 = 0; k4 < COMB_ENTRY_WORDS / 4; ++k4) { u32x4 v = p[k4]; w[4 * k4] = v.x; w[4 * k4 + 1] = v.y; w[4 * k4 + 2] = v.z; w[4 * k4 + 3] = v.w; }
+        fe_t ypx, ymx, t2d;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { ypx.l[j] = w[j]; ymx.l[j] = w[9 + j]; t2d.l[j] = w[18 + j]; }
+        acc = ext_add_affine_niels(acc, ypx, ymx, t2d, i != COMB_WINDOWS - 1);
+    }
+    return acc;
+}
+JJS_HD words8 widen128(const u128w& x) {
+    words8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.w[i] = i < 4 ? x.w[i] : 0u;
+    return r;
+}
+// x + 0x0888...8 over 32 nibbles: signed digits for a scalar below 2^127 (top digit 31 unsigned)
+JJS_HD words8 recode_signed4_128(const u128w& s) {
+    words8 r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)(i < 4 ? s.w[i] : 0u) + (i < 3 ? 0x88888888u : (i == 3 ? 0x08888888u : 0u)) + carry;
+        r.w[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    return r;
+}
+
+JJS_HD words8 select_words(bool c, const words8& a, const words8& b) {
+    words8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.w[i] = c ? a.w[i] : b.w[i];
+    return r;
+}
+
+// u*Gen + c*PK == R.
+//  * Fixed generator (comb table present), through half-size scalars:
+//      (b*u mod r)*G + a*PK - b*R == O   with a = b*c (mod r), a, |b| < 2^126,
+//    which is equivalent to the reference's equation whenever PK and R have order r -- and when they
+//    do not the item is InvalidPoint whatever this returns.  Two per-lane tables (PK, R), 124 shared
+//    doublings, then the comb additions for (b*u)*G.
+//  * Per-item generator: Straus over two per-lane tables (PK, Gen), 252 shared doublings, compared
+//    with R projectively.
+// Both cases run the same window loop (one copy of the doubling and addition code in the kernel).
 JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const words8& u, const words8& c) {
-    uint32_t* tab_pk = ws;
-    uint32_t* tab_gen = ws + TABLE_WORDS;
-    {
-        fe_n pu = load_fq(E.pk, item), pv = load_fq(E.pk, item, 32);
-        build_point_table(tab_pk, pu, pv);
+    const bool fixed = (E.comb != nullptr);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {                       // table 0: PK; table 1: R (fixed) or Gen
+        const fe_src& src = (t == 0) ? E.pk : (fixed ? E.r : E.gen);
+        fe_n pu = load_fq(src, item), pv = load_fq(src, item, 32);
+        build_point_table(ws + t * TABLE_WORDS, pu, pv);
     }
-    const bool varbase = (E.comb == nullptr);
-    words8 su;
-    if (varbase) {
-        fe_n gu = load_fq(E.gen, item), gv = load_fq(E.gen, item, 32);
-        build_point_table(tab_gen, gu, gv);
-        su = recode_signed4(u);
+    words8 s0, s1, w;
+    int top;
+    bool flip1;
+    if (fixed) {
+        const half_scalars h = half_size_scalars(c);
+        words8 r2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
+        w = fr_mont_mul(fr_mont_mul(widen128(h.b), r2), u);          // |b|*u mod r
+        uint32_t nz = 0, borrow = 0;
+        words8 n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            nz |= w.w[i];
+            uint64_t d = (uint64_t)JJS_FR_WORDS[i] - w.w[i] - borrow;
+            n.w[i] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+        }
+        w = select_words(h.b_neg && nz != 0, n, w);                   // b*u mod r
+        s0 = recode_signed4_128(h.a);
+        s1 = recode_signed4_128(h.b);
+        top = 31;
+        flip1 = !h.b_neg;                                             // table 1 contributes -b*R
+    } else {
+        s0 = recode_signed4(c);
+        s1 = recode_signed4(u);
+        w = u;
+        top = 63;
+        flip1 = false;
     }
-    const words8 sc = recode_signed4(c);
     ext_pt acc = ext_identity();
-    for (int w = 63; w >= 0; --w) {
-        if (w != 63) {
-            acc = ext_double(acc, false);
-            acc = ext_double(acc, false);
-            acc = ext_double(acc, false);
-            acc = ext_double(acc, true);
+    for (int win = top; win >= 0; --win) {
+        if (win != top) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) acc = ext_double(acc, j == 3);
         }
-        if (varbase) {
-            acc = add_window(acc, tab_pk, sc, w, true);
-            acc = add_window(acc, tab_gen, su, w, false);
-        } else {
-            acc = add_window(acc, tab_pk, sc, w, w == 0);
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            const words8 sc = select_words(t == 0, s0, s1);
+            const bool need_t = (t == 0) || (fixed && win == 0);      // comb additions follow the last window
+            acc = add_window(acc, ws + t * TABLE_WORDS, sc, win, need_t, top, t == 1 && flip1);
         }
     }
-    if (!varbase) {
-        for (int i = 0; i < COMB_WINDOWS; ++i) {
-            uint32_t byte = (word_at(u, i >> 2) >> ((i & 3) * 8)) & 255u;
-            const u32x4* p = reinterpret_cast<const u32x4*>(E.comb + ((size_t)i * COMB_ENTRIES + byte) * COMB_ENTRY_WORDS);
-            uint32_t w[COMB_ENTRY_WORDS];
-#pragma unroll
-            for (int k = 0; k < COMB_ENTRY_WORDS / 4; ++k) { u32x4 v = p[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-            fe_t ypx, ymx, t2d;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { ypx.l[k] = w[k]; ymx.l[k] = w[9 + k]; t2d.l[k] = w[18 + k]; }
-            acc = ext_add_affine_niels(acc, ypx, ymx, t2d, i != COMB_WINDOWS - 1);
-        }
+    if (fixed) {
+        acc = add_comb(acc, E.comb, w);
+        return ext_is_identity(acc);
     }
     fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
     return ext_eq_affine(acc, ru, rv);

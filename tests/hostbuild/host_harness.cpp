@@ -99,6 +99,17 @@ int jjs_host_point_flags(const uint8_t* P, size_t n, uint8_t* out) {
     }
     return 0;
 }
+// c (n x 32) -> a (16 bytes) || |b| (16 bytes) || sign byte, 33 bytes per item
+int jjs_host_half_size(const uint8_t* c, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 w;
+        memcpy(w.w, c + 32 * i, 32);
+        half_scalars h = half_size_scalars(w);
+        memcpy(out + 33 * i, h.a.w, 16); memcpy(out + 33 * i + 16, h.b.w, 16);
+        out[33 * i + 32] = h.b_neg ? 1 : 0;
+    }
+    return 0;
+}
 // comb table entry -> affine point bytes (u || v), recovered from the cached form
 int jjs_host_comb_entry(int which, int i, int b, uint8_t* out_ypx_ymx_t2d) {
     ensure_tables();

@@ -84,3 +84,8 @@ def verify(scheme, b, want_c=False):
     fn = getattr(load(), "jjs_host_verify_" + scheme)
     fn(*[_p(a) for a in args], ctypes.c_size_t(n), _p(st), _p(tally), _p(c))
     return (st, tally, c) if want_c else (st, tally)
+
+
+def half_size(c):
+    c = _c(c); out = np.empty((len(c), 33), np.uint8)
+    load().jjs_host_half_size(_p(c), ctypes.c_size_t(len(c)), _p(out)); return out

@@ -81,3 +81,22 @@ def test_verify_matches_oracle_on_edge_cases(scheme):
     want = oracle_verify(scheme, b)
     st, _ = hl.verify(scheme, b)
     assert st.tolist() == want.tolist()
+
+
+def test_half_size_scalars():
+    """a = b*c (mod r) with a, |b| < 2^126, for random and adversarial c."""
+    rng = np.random.default_rng(12)
+    c = rand_mod(rng, 400, 1 << 250)
+    specials = [0, 1, 2, (1 << 126) - 1, 1 << 126, (1 << 126) + 1, (1 << 250) - 1, o.R_ORDER - 1, o.R_ORDER // 2,
+                (o.R_ORDER + 1) // 2, 1 << 127, 1 << 200, 3 << 248, o.R_ORDER - (1 << 126), (1 << 125) + 12345]
+    for i, x in enumerate(specials):
+        c[i] = fe_bytes(x)
+    out = hl.half_size(c)
+    for i in range(len(c)):
+        ci = to_int(c[i])
+        a = int.from_bytes(out[i, :16].tobytes(), "little")
+        b = int.from_bytes(out[i, 16:32].tobytes(), "little")
+        if out[i, 32]:
+            b = -b
+        assert 0 <= a < 1 << 126 and 0 < abs(b) < 1 << 126, (i, a, b)
+        assert (a - b * ci) % o.R_ORDER == 0, i
