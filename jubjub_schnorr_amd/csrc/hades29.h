@@ -6,7 +6,7 @@
 // Cauchy matrix as generated into jjs_constants.inc.  Constants are read at wave-uniform addresses
 // (scalar cache, SGPR operands); each matrix row is ONE five-term dot product with a single
 // Montgomery reduction (fq_dot_const) instead of five reduced products, and the 60 partial rounds use
-// the sparse-matrix form.
+// the controller-canonical form (two dot products per round).
 #pragma once
 #include "fq29.h"
 
@@ -23,10 +23,12 @@ JJS_HD fe_n sbox5(const fe<L, A>& x) {
     return fq_mul(x4, x);
 }
 
-// The permutation in its optimised form (constants: optimised_hades() in tools/gen_constants.py):
-// every partial round adds ONE constant (lane 4), applies the S-box to lane 4 and a sparse matrix --
-// lane 4 becomes a five-term dot product, lanes 0..3 each gain col[i] * sbox -- and the dense matrix
-// appears only in the 8 full rounds and after the last partial round.  Same function of the state as
+// The permutation in its optimised form (constants and derivation: optimised_hades() in
+// tools/gen_constants.py).  The 60 partial rounds are the time-invariant linear system
+// p' = Mh p + v x, y' = w.p + m44 x driven by x = (y + kappa)^5; in controller canonical form a round is
+// one S-box, TWO five-term dot products (new z3, new y) and a register shift, and only one constant is
+// added.  The dense matrix appears in the 8 full rounds and in the last partial round, with the change
+// of basis folded into the matrices on both sides of the partial block.  Same function of the state as
 // the textbook round sequence (checked in the generator, on the host build and on the GPU).
 JJS_HD void hades_permute(hades_state& st) {
     // nine dense-mix events: full rounds 0..3, the last partial round, full rounds 4..7
@@ -35,23 +37,27 @@ JJS_HD void hades_permute(hades_state& st) {
         const uint32_t (*mat)[5][9];   // mat[i] = row i, a 5 x 9 block of limbs
         if (ev == 4) {
             for (int k = 0; k < 59; ++k) {
-                fe_n x4 = sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HP_KAPPA[k])));
-                fe_n v[5] = {st.s[0], st.s[1], st.s[2], st.s[3], x4};
-                fe_n n4 = fq_dot_const<5, 2>(JJS_HP_ROW[k], v);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    st.s[i] = fq_reduce(fq_norm(fq_add(st.s[i], fq_mul(x4, fe_from_const<1, 1>(JJS_HP_COL[k][i])))));
-                st.s[4] = n4;
+                fe_n v[5] = {st.s[0], st.s[1], st.s[2], st.s[3],
+                             sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HP_KAPPA[k])))};
+                // new z3 then new y from ONE copy of the dot-product code (a rolled loop also keeps the
+                // compiler from hoisting both constant rows into 90 SGPRs across the round loop)
+                fe_n z3 = v[4], y = v[4];
+#pragma unroll 1
+                for (int r = 0; r < 2; ++r) {
+                    z3 = y;
+                    y = fq_dot_const<5, 2>(JJS_HP_ROWS[r], v);
+                }
+                st.s[0] = st.s[1]; st.s[1] = st.s[2]; st.s[2] = st.s[3]; st.s[3] = z3; st.s[4] = y;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
             t[4] = sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HP_KAPPA[59])));
-            mat = JJS_HP_LAST;
+            mat = JJS_HD_MAT[2];
         } else {
             const int fr = ev < 4 ? ev : ev - 1;
 #pragma unroll
             for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HF_RC[fr][i])));
-            mat = JJS_MDS;
+            mat = JJS_HD_MAT[ev == 3 ? 1 : 0];
         }
         // One copy of the dot-product code: rows are produced in order into s[4] while the state
         // registers rotate down, so after five steps s[i] holds row i (static indices only).

@@ -21,7 +21,8 @@ namespace {
 
 constexpr int BLOCK = 256;
 
-__global__ __launch_bounds__(BLOCK) void verify_kernel(verify_params P) {
+// second launch-bound argument: at least 2 waves per SIMD, i.e. at most 256 registers per lane
+__global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     uint32_t* ws = P.workspace + gtid * WS_WORDS_PER_LANE;

@@ -263,6 +263,14 @@ JJS_HD void shl_words(uint32_t (&x)[N], int d) {
     }
 }
 template <int N>
+JJS_HD void shl_bits(uint32_t (&x)[N], int bs) {   // 0 <= bs < 32
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        uint64_t v = ((uint64_t)x[i] << 32) | (i ? x[i - 1] : 0u);
+        x[i] = (uint32_t)((v << bs) >> 32);
+    }
+}
+template <int N>
 JJS_HD void shr1_words(uint32_t (&x)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = (x[i] >> 1) | (i + 1 < N ? x[i + 1] << 31 : 0u);
@@ -300,8 +308,12 @@ JJS_HD half_scalars half_size_scalars(const words8& c) {
         for (int i = 0; i < 8; ++i) x[i] = r1[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = t1[i];
-        shl_words(x, d);
-        shl_words(y, d);
+        if (wave_any(d >= 32)) {          // rare: a huge partial quotient somewhere in the wave
+            shl_words(x, d & ~31);
+            shl_words(y, d & ~31);
+        }
+        shl_bits(x, d & 31);
+        shl_bits(y, d & 31);
         if (lt_words(r0, x)) { shr1_words(x); shr1_words(y); }   // only possible when d >= 1
         uint32_t n0[8], m0[4];
         uint32_t borrow = 0, carry = 0;
@@ -375,7 +387,18 @@ JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
     fe_n y2 = fq_sqr(y);
     fe_n y7 = fq_mul(fq_mul(fq_sqr(y2), y2), y);
     fe_n g = fq_mul(a, y7);
-    fe_n e = fq_pow_public(g, JJS_PAIR_EXP_WORDS, 252);
+    // g^((q-1)/8) by a public sliding-window schedule (width 3: g, g^3, g^5, g^7 in registers)
+    fe_n g2 = fq_sqr(g);
+    fe_n g3 = fq_mul(g2, g), g5 = fq_mul(g3, g2), g7 = fq_mul(g5, g2);
+    fe_n e = fe_n_one();
+    for (int st = 0; st < JJS_PAIR_SW_STEPS; ++st) {
+        const uint32_t nsq = JJS_PAIR_SW[st][0], dg = JJS_PAIR_SW[st][1];
+        if (st != 0)
+            for (uint32_t j = 0; j < nsq; ++j) e = fq_sqr(e);
+        const fe_n m = fq_select(dg == 1, g, fq_select(dg == 3, g3, fq_select(dg == 5, g5, g7)));
+        e = (st == 0) ? m : fq_mul(e, m);
+    }
+    for (int j = 0; j < JJS_PAIR_SW_TRAILING; ++j) e = fq_sqr(e);
     return fq_eq(e, fq_one());
 }
 

@@ -71,14 +71,18 @@ def sponge_tag(n_in, n_out=1, domain=0):
     return int.from_bytes(hashlib.blake2b(data, digest_size=64).digest(), "little") % Q
 
 
-# ---- optimised Hades: one constant and one sparse matrix per partial round ---------------------------
-# Partial round r:  x += c_r ; x[4] = x[4]^5 ; x = M x.   Two rewrites, both exact:
-#  (1) the constants on lanes 0..3 commute with the S-box, so M * (c_r with lane 4 zeroed) is pushed
-#      into c_{r+1}; only a scalar kappa_r on lane 4 remains per round and the last carry is folded into
-#      the constants of the first full round that follows;
-#  (2) with lane 4 first, M_k = [[a, w^T], [v, Mh]] = diag(1, Mh) * [[a, w^T], [Mh^-1 v, I]] = A_k B_k and
-#      A_k commutes with the next round's S-box, so round k applies only the sparse B_k and
-#      M_{k+1} = M * A_k; the last partial round applies the dense M_60.
+# ---- optimised Hades --------------------------------------------------------------------------------------
+# Partial round r (lanes 0..3 = p, lane 4 = y):  x = (y + c_r[4])^5 after adding c_r;  then M.  Two exact rewrites:
+#  (1) the constants on lanes 0..3 commute with the S-box, so M * (c_r with lane 4 zeroed) is pushed into
+#      c_{r+1}; only a scalar kappa_r on lane 4 remains per round and the last carry is folded into the
+#      constants of the first full round that follows;
+#  (2) with M = [[Mh, v], [w^T, m44]] the partial rounds are the time-invariant linear system
+#      p' = Mh p + v x,  y' = w.p + m44 x.  In the basis T = [t0 t1 t2 t3] with t3 = v,
+#      t_{i-1} = Mh t_i + alpha_i t3 (alpha = characteristic polynomial of Mh) the system is in controller
+#      canonical form: z0' = z1, z1' = z2, z2' = z3, z3' = -alpha.z + x, y' = (T^T w).z + m44 x, i.e. TWO
+#      five-term dot products per round and a register shift.  The change of basis is folded into the dense
+#      matrices on both sides: diag(T^-1, 1) M after the last leading full round, M diag(T, 1) in the last
+#      partial round.
 def mat_mul(a, b):
     return [[sum(a[i][k] * b[k][j] for k in range(len(b))) % Q for j in range(len(b[0]))] for i in range(len(a))]
 
@@ -102,6 +106,10 @@ def mat_inv(a):
     return [r[n:] for r in m]
 
 
+def block_diag1(t):
+    return [list(r) + [0] for r in t] + [[0, 0, 0, 0, 1]]
+
+
 def optimised_hades():
     rc, m = round_constants(), mds()
     half = N_FULL // 2
@@ -113,15 +121,29 @@ def optimised_hades():
         carry = mat_vec(m, cr[:4] + [0])
     full = [list(c[r]) for r in range(half)] + [list(c[r]) for r in range(half + N_PARTIAL, N_ROUNDS)]
     full[half] = [(x + y) % Q for x, y in zip(full[half], carry)]
-    rows, cols, mk = [], [], m
-    for k in range(N_PARTIAL - 1):
-        mh = [r[:4] for r in mk[:4]]                      # lanes 0..3 x lanes 0..3
-        v = [mk[i][4] for i in range(4)]                  # lane 4 -> lanes 0..3
-        rows.append(list(mk[4]))                          # new lane 4 = <row, x>
-        cols.append(mat_vec(mat_inv(mh), v))              # lane i += col[i] * x[4]
-        ak = [mh[i] + [0] for i in range(4)] + [[0, 0, 0, 0, 1]]
-        mk = mat_mul(m, ak)
-    return kappa, full, rows, cols, mk
+    mh = [r[:4] for r in m[:4]]
+    v = [m[i][4] for i in range(4)]
+    w = m[4][:4]
+    # characteristic polynomial through the Krylov vectors of v
+    kry = [v]
+    for _ in range(4):
+        kry.append(mat_vec(mh, kry[-1]))
+    kmat = [[kry[j][i] for j in range(4)] for i in range(4)]            # columns v, Mh v, Mh^2 v, Mh^3 v
+    alpha = [(-x) % Q for x in mat_vec(mat_inv(kmat), kry[4])]          # Mh^4 v = -sum alpha_j Mh^j v
+    t = [None, None, None, v]
+    for i in (3, 2, 1):
+        mv = mat_vec(mh, t[i])
+        t[i - 1] = [(a + alpha[i] * b) % Q for a, b in zip(mv, v)]
+    tm = [[t[j][i] for j in range(4)] for i in range(4)]                # T, columns t0..t3
+    ti = mat_inv(tm)
+    comp = mat_mul(mat_mul(ti, mh), tm)
+    want = [[0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [(-a) % Q for a in alpha]]
+    assert comp == want and mat_vec(ti, v) == [0, 0, 0, 1], "controller canonical form not reached"
+    row_z3 = [(-a) % Q for a in alpha] + [1]
+    row_y = [sum(w[i] * tm[i][j] for i in range(4)) % Q for j in range(4)] + [m[4][4]]
+    m_pre = mat_mul(block_diag1(ti), m)
+    m_last = mat_mul(m, block_diag1(tm))
+    return kappa, full, row_z3, row_y, m_pre, m_last
 
 
 def hades_reference(state):
@@ -137,16 +159,17 @@ def hades_reference(state):
     return s
 
 
-def hades_optimised(state, kappa, full, rows, cols, m_last):
+def hades_optimised(state, kappa, full, row_z3, row_y, m_pre, m_last):
     m, s, half = mds(), list(state), N_FULL // 2
     for r in range(half):
-        s = mat_vec(m, [pow((x + full[r][i]) % Q, 5, Q) for i, x in enumerate(s)])
+        s = mat_vec(m_pre if r == half - 1 else m, [pow((x + full[r][i]) % Q, 5, Q) for i, x in enumerate(s)])
     for k in range(N_PARTIAL):
-        x4 = pow((s[4] + kappa[k]) % Q, 5, Q)
+        x = pow((s[4] + kappa[k]) % Q, 5, Q)
+        vec = s[:4] + [x]
         if k < N_PARTIAL - 1:
-            s = [(s[i] + cols[k][i] * x4) % Q for i in range(4)] + [(sum(rows[k][j] * s[j] for j in range(4)) + rows[k][4] * x4) % Q]
+            s = [s[1], s[2], s[3], sum(a * b for a, b in zip(row_z3, vec)) % Q, sum(a * b for a, b in zip(row_y, vec)) % Q]
         else:
-            s = mat_vec(m_last, s[:4] + [x4])
+            s = mat_vec(m_last, vec)
     for r in range(half, N_FULL):
         s = mat_vec(m, [pow((x + full[r][i]) % Q, 5, Q) for i, x in enumerate(s)])
     return s
@@ -171,6 +194,29 @@ def ed_add(p1, p2):
     (u1, v1), (u2, v2) = p1, p2
     t = D * u1 * u2 % Q * v1 * v2 % Q
     return ((u1 * v2 + v1 * u2) * inv(1 + t) % Q, (v1 * v2 + u1 * u2) * inv(1 - t) % Q)
+
+
+def sliding_window_schedule(e, width):
+    """e = sum of digit * 2^pos: steps (squarings before the multiply, odd digit), then trailing squarings.
+    Evaluating: acc = 1; for (n, d): acc = acc^(2^n) * g^d; finally acc = acc^(2^trailing)."""
+    steps, pending, i = [], 0, e.bit_length() - 1
+    while i >= 0:
+        if not (e >> i) & 1:
+            pending += 1
+            i -= 1
+            continue
+        j = max(i - width + 1, 0)
+        while not (e >> j) & 1:
+            j += 1
+        digit = (e >> j) & ((1 << (i - j + 1)) - 1)
+        steps.append((pending + (i - j + 1), digit))
+        pending = 0
+        i = j - 1
+    acc = 0
+    for n, dg in steps:
+        acc = (acc << n) + dg
+    assert acc << pending == e and all(dg & 1 and dg < (1 << width) for _, dg in steps)
+    return steps, pending
 
 
 def pairing_constants():
@@ -226,13 +272,18 @@ def main():
     L.append("JJS_CONST uint32_t JJS_PAIR_NEG_L2[9] = %s;" % limbs29(mont(pc["NEG_L2"])))
     L.append("JJS_CONST uint32_t JJS_PAIR_B[9] = %s;" % limbs29(mont(pc["B"])))
     L.append("JJS_CONST uint32_t JJS_PAIR_EXP_WORDS[8] = %s;  // (q - 1) / 8" % words32((Q - 1) // 8))
+    steps, trailing = sliding_window_schedule((Q - 1) // 8, 3)
+    L.append("// (q - 1) / 8 as a left-to-right sliding-window (width 3) schedule: {squarings, odd digit} per step")
+    L.append("#define JJS_PAIR_SW_STEPS %d" % len(steps))
+    L.append("#define JJS_PAIR_SW_TRAILING %d" % trailing)
+    L.append("JJS_CONST uint32_t JJS_PAIR_SW[JJS_PAIR_SW_STEPS][2] = {" + ", ".join("{%d, %d}" % st for st in steps) + "};")
     L.append("JJS_CONST uint32_t JJS_RC[%d][9] = {" % len(rc))
     L += ["  %s," % limbs29(mont(c)) for c in rc]
     L.append("};")
-    kappa, full, rows, cols, m_last = optimised_hades()
+    kappa, full, row_z3, row_y, m_pre, m_last = optimised_hades()
     for trial in range(3):
         st = [int.from_bytes(hashlib.sha256(b"hades-selfcheck-%d-%d" % (trial, i)).digest(), "little") % Q for i in range(WIDTH)]
-        assert hades_reference(st) == hades_optimised(st, kappa, full, rows, cols, m_last), "optimised Hades differs"
+        assert hades_reference(st) == hades_optimised(st, kappa, full, row_z3, row_y, m_pre, m_last), "optimised Hades differs"
     L.append("// optimised Hades (see optimised_hades() in the generator)")
     L.append("JJS_CONST uint32_t JJS_HF_RC[%d][5][9] = {" % N_FULL)
     L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in full]
@@ -240,14 +291,17 @@ def main():
     L.append("JJS_CONST uint32_t JJS_HP_KAPPA[%d][9] = {" % N_PARTIAL)
     L += ["  %s," % limbs29(mont(x)) for x in kappa]
     L.append("};")
-    L.append("JJS_CONST uint32_t JJS_HP_ROW[%d][5][9] = {" % (N_PARTIAL - 1))
-    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in rows]
+    L.append("// partial rounds in controller canonical form: rows for z3' and y' over (z0, z1, z2, z3, x)")
+    L.append("JJS_CONST uint32_t JJS_HP_ROWS[2][5][9] = {")
+    for row in (row_z3, row_y):
+        L.append("  {" + ", ".join(limbs29(mont(x)) for x in row) + "},")
     L.append("};")
-    L.append("JJS_CONST uint32_t JJS_HP_COL[%d][4][9] = {" % (N_PARTIAL - 1))
-    L += ["  {" + ", ".join(limbs29(mont(x)) for x in col) + "}," for col in cols]
-    L.append("};")
-    L.append("JJS_CONST uint32_t JJS_HP_LAST[5][5][9] = {")
-    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in m_last]
+    L.append("// dense matrices: [0] = MDS, [1] = diag(T^-1,1) MDS (enters the canonical basis), [2] = MDS diag(T,1) (leaves it)")
+    L.append("JJS_CONST uint32_t JJS_HD_MAT[3][5][5][9] = {")
+    for mat in (m, m_pre, m_last):
+        L.append(" {")
+        L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in mat]
+        L.append(" },")
     L.append("};")
     L.append("JJS_CONST uint32_t JJS_MDS[5][5][9] = {")
     for i in range(WIDTH):

@@ -60,3 +60,15 @@ def test_poseidon_constants():
     mds = arrays("JJS_MDS")
     assert len(mds) == 25
     assert [limbs(r) for r in mds] == [mont(o.MDS[i][j]) for i in range(5) for j in range(5)]
+
+
+def test_optimised_hades_tables_are_consistent():
+    """The optimised permutation is checked end to end by the Poseidon parity tests; here: shapes, the
+    plain MDS copy, and that the canonical-form rows are what the generator's own model uses."""
+    mats = arrays("JJS_HD_MAT")
+    assert len(mats) == 75
+    assert [limbs(r) for r in mats[:25]] == [mont(o.MDS[i][j]) for i in range(5) for j in range(5)]
+    assert len(arrays("JJS_HP_KAPPA")) == 60 and len(arrays("JJS_HP_ROWS")) == 10 and len(arrays("JJS_HF_RC")) == 40
+    rows = arrays("JJS_HP_ROWS")
+    assert limbs(rows[4]) == mont(1)                      # z3' = -alpha.z + 1*x
+    assert limbs(rows[9]) == mont(o.MDS[4][4])            # y'  = (T^T w).z + m44*x
