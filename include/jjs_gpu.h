@@ -116,6 +116,9 @@ int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* 
 /* out[i] bit0 = on curve, bit1 = torsion free (pairing test, as used by verify; identity counts as
  * torsion free), bit2 = identity, bit3 = torsion free by the reference's definition [r]P == O */
 int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream);
+/* profiling ablations ONLY (results become meaningless): skip phases of the verify kernel in later
+ * launches; bit0 = point validity, bit1 = challenge hash, bit2 = equations; 0 restores production. */
+int jjs_debug_skip_phases(unsigned mask);
 /* copies the fixed-base table of G (which = 0) or G' (which = 1) to host memory; size in bytes via
  * jjs_debug_comb_table_bytes() */
 size_t jjs_debug_comb_table_bytes(void);

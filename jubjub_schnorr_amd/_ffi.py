@@ -34,6 +34,7 @@ SIGNATURES = {
     "jjs_debug_fq_mul_dev": [_P, _P, _Z, _P, _P],
     "jjs_debug_poseidon_dev": [_P, _Z, _Z, _P, _P],
     "jjs_debug_point_flags_dev": [_P, _Z, _P, _P],
+    "jjs_debug_skip_phases": [ctypes.c_uint],
     "jjs_debug_comb_table_bytes": [],
     "jjs_debug_comb_table": [_I, _P],
 }

@@ -302,6 +302,31 @@ JJS_HD fe_n fq_dot_const(const uint32_t (*c)[9], const fe<1, As>* s) {
     return r;
 }
 
+// (sum_j s[j] * t[j]) / 2^29 mod q for small public scalars s[j] < 2^17 (wave-uniform, SGPR operands):
+// K*9 small-scalar multiply-adds plus ONE Montgomery row (the quotient digit of the lowest column).
+// Columns stay below K*L*2^46 + 2^58; the result is below (K * 2^17 * A / 2^29 + 1) q < 2q.
+template <int K, int L, int A>
+JJS_HD fe_n fq_lincomb_small(const uint32_t* s, const fe<L, A>* t) {
+    static_assert(K * L <= 1024 && K * A <= 2048, "small linear combination out of range");
+    fe_n r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc += (uint64_t)s[j] * t[j].l[0];
+    const uint32_t m = (0u - (uint32_t)acc) & MASK29;
+    acc += m;
+    acc >>= 29;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += (uint64_t)s[j] * t[j].l[k];
+        acc += (uint64_t)m * q29(k);
+        r.l[k - 1] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // conversions between 8 x 32-bit canonical words and the internal form
 // ---------------------------------------------------------------------------------------------

@@ -4,9 +4,7 @@
 // src/signatures/double.rs:162 and src/signatures/var_gen.rs:130.  Parameterisation per SURVEY.md A.3:
 // 4 full + 60 partial + 4 full rounds, S-box x^5 on state[4] in partial rounds, round constants and
 // Cauchy matrix as generated into jjs_constants.inc.  Constants are read at wave-uniform addresses
-// (scalar cache, SGPR operands); each matrix row is ONE five-term dot product with a single
-// Montgomery reduction (fq_dot_const) instead of five reduced products, and the 60 partial rounds use
-// the controller-canonical form (two dot products per round).
+// (scalar cache, SGPR operands); the matrix is applied in its small-integer form.
 #pragma once
 #include "fq29.h"
 
@@ -23,50 +21,34 @@ JJS_HD fe_n sbox5(const fe<L, A>& x) {
     return fq_mul(x4, x);
 }
 
-// The permutation in its optimised form (constants and derivation: optimised_hades() in
-// tools/gen_constants.py).  The 60 partial rounds are the time-invariant linear system
-// p' = Mh p + v x, y' = w.p + m44 x driven by x = (y + kappa)^5; in controller canonical form a round is
-// one S-box, TWO five-term dot products (new z3, new y) and a register shift, and only one constant is
-// added.  The dense matrix appears in the 8 full rounds and in the last partial round, with the change
-// of basis folded into the matrices on both sides of the partial block.  Same function of the state as
-// the textbook round sequence (checked in the generator, on the host build and on the GPU).
+// The permutation (constants and derivation: scaled_hades_constants() in tools/gen_constants.py).
+// The MDS matrix is Cauchy, M[i][j] = F / (i + j + 5); with L = lcm(5..13) = 360360 it is (F/L) * S for a
+// matrix S of INTEGERS below 2^17, so a matrix row is 45 small multiply-adds plus one Montgomery row
+// (fq_lincomb_small) instead of a dot product with five 255-bit constants.  The scalar F/L * 2^29 is
+// never multiplied in: the state is carried as s = lambda_r * s~ for a public per-round scale that passes
+// through the S-box as lambda^5 and lives in the pre-scaled round constants; in a partial round lane 4
+// is brought back to the common scale by one product with lambda_r^4, and constants on lanes 0..3 have
+// been pushed forward so that only lane 4 receives one.  After round 68 the state is multiplied by
+// lambda_end.  Same function of the state as the textbook round sequence (checked in the generator, on
+// the host build and on the GPU).
 JJS_HD void hades_permute(hades_state& st) {
-    // nine dense-mix events: full rounds 0..3, the last partial round, full rounds 4..7
-    for (int ev = 0; ev < 9; ++ev) {
+    for (int r = 0; r < 68; ++r) {
         fe_n t[5];
-        const uint32_t (*mat)[5][9];   // mat[i] = row i, a 5 x 9 block of limbs
-        if (ev == 4) {
-            for (int k = 0; k < 59; ++k) {
-                fe_n v[5] = {st.s[0], st.s[1], st.s[2], st.s[3],
-                             sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HP_KAPPA[k])))};
-                // new z3 then new y from ONE copy of the dot-product code (a rolled loop also keeps the
-                // compiler from hoisting both constant rows into 90 SGPRs across the round loop)
-                fe_n z3 = v[4], y = v[4];
-#pragma unroll 1
-                for (int r = 0; r < 2; ++r) {
-                    z3 = y;
-                    y = fq_dot_const<5, 2>(JJS_HP_ROWS[r], v);
-                }
-                st.s[0] = st.s[1]; st.s[1] = st.s[2]; st.s[2] = st.s[3]; st.s[3] = z3; st.s[4] = y;
-            }
+        if (r < 4 || r >= 64) {
+            const int fr = r < 4 ? r : r - 60;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i])));
+        } else {
+            const int k = r - 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
-            t[4] = sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HP_KAPPA[59])));
-            mat = JJS_HD_MAT[2];
-        } else {
-            const int fr = ev < 4 ? ev : ev - 1;
+            t[4] = fq_mul(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k]))), fe_from_const<1, 1>(JJS_HS_MU[k]));
+        }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HF_RC[fr][i])));
-            mat = JJS_HD_MAT[ev == 3 ? 1 : 0];
-        }
-        // One copy of the dot-product code: rows are produced in order into s[4] while the state
-        // registers rotate down, so after five steps s[i] holds row i (static indices only).
-#pragma unroll 1
-        for (int i = 0; i < 5; ++i) {
-            fe_n row = fq_dot_const<5, 2>(mat[i], t);
-            st.s[0] = st.s[1]; st.s[1] = st.s[2]; st.s[2] = st.s[3]; st.s[3] = st.s[4]; st.s[4] = row;
-        }
+        for (int i = 0; i < 5; ++i) st.s[i] = fq_lincomb_small<5>(JJS_HS_MAT[i], t);
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st.s[i] = fq_mul(st.s[i], fe_from_const<1, 1>(JJS_HS_LAMBDA_END));
 }
 
 // Absorbs n_inputs elements fetched through `fetch(e)` (which returns the Montgomery form of

@@ -130,8 +130,11 @@ int grid_for(int resident, size_t n) {
     return (int)(want < (size_t)resident ? want : (size_t)resident);
 }
 
+uint32_t g_skip_phases = 0;   // set by jjs_debug_skip_phases (profiling ablations only)
+
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
+    P.skip_phases = g_skip_phases;
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g.grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
     return JJS_OK;
@@ -433,6 +436,11 @@ int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* str
     hipLaunchKernelGGL(dbg_point_flags_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
                        (const uint8_t*)points, (uint64_t)n, (uint8_t*)out);
     HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int jjs_debug_skip_phases(unsigned mask) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    g_skip_phases = mask & 7u;
     return JJS_OK;
 }
 size_t jjs_debug_comb_table_bytes(void) { return COMB_TABLE_WORDS * sizeof(uint32_t); }

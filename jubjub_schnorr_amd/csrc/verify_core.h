@@ -39,7 +39,8 @@ struct eq_desc {           // u*Gen + c*PK == R
     fe_src r;
 };
 struct verify_params {
-    uint32_t n_hash, n_points, n_eq, pad_;
+    uint32_t n_hash, n_points, n_eq;
+    uint32_t skip_phases;            // profiling only (bit0 validity, bit1 challenge, bit2 equations); 0 in production
     fe_src hash_in[10];
     fe_src points[4];
     eq_desc eq[2];
@@ -527,19 +528,22 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
     bool valid = true;
-    for (uint32_t k = 0; k < P.n_points; ++k) {
+    for (uint32_t k = 0; k < ((P.skip_phases & 1u) ? 0u : P.n_points); ++k) {
         fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
         valid = point_is_valid(pu, pv) && valid;
     }
 
     // 3. challenge
-    fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
-    const words8 c = truncate250(digest);
+    words8 c = u;
+    if (!(P.skip_phases & 2u)) {
+        fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
+        c = truncate250(digest);
+    }
     if (P.c_out && write_c) store_words(P.c_out, item, c);
 
     // 4. equations
     bool eq_ok = true;
-    for (uint32_t k = 0; k < P.n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, c) && eq_ok;
+    for (uint32_t k = 0; k < ((P.skip_phases & 4u) ? 0u : P.n_eq); ++k) eq_ok = check_equation(P.eq[k], item, ws, u, c) && eq_ok;
 
     return malformed ? ST_MALFORMED : (!valid ? ST_INVALID_POINT : (!eq_ok ? ST_INVALID_SIGNATURE : ST_OK));
 }

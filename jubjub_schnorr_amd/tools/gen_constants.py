@@ -175,6 +175,55 @@ def hades_optimised(state, kappa, full, row_z3, row_y, m_pre, m_last):
     return s
 
 
+# ---- Hades with a small-integer matrix ----------------------------------------------------------------------
+# The MDS matrix is Cauchy: M[i][j] = F / (i + j + 5) with F = 2^256 mod q.  With L = lcm(5..13) = 360360,
+# M = (F / L) * S where S[i][j] = L / (i + j + 5) is an INTEGER below 2^17.  A row of S times the state is 5
+# small-scalar x 9-limb products (45 multiply-adds) plus one Montgomery row to drop 29 bits, instead of a
+# 5-term dot product with 255-bit constants (477 multiply-adds).  The scalar F/L (and the 2^-29 of the
+# single Montgomery row) is never multiplied in: the state is kept as s = lambda_r * s~ with a public
+# per-round scale lambda_r, which passes through the S-box as lambda^5 and is absorbed into pre-scaled
+# round constants.  In partial rounds only lane 4 goes through the S-box, so it is brought back to the
+# common scale by one multiplication with lambda_r^4.  After the last round the state is multiplied by
+# lambda_end once.
+SMALL_L = 360360
+SMALL_S = [[SMALL_L // (i + j + 5) for j in range(WIDTH)] for i in range(WIDTH)]
+INV_2_29 = inv(1 << 29)
+
+
+def scaled_hades_constants():
+    kappa, full, _, _, _, _ = optimised_hades()          # forward-pushed constants (true domain)
+    f_over_l = POSEIDON_FACTOR * inv(SMALL_L) % Q
+    step = f_over_l * (1 << 29) % Q                        # out_true = step * lambda' * rho
+    half = N_FULL // 2
+    lam = 1
+    rc_full, kap, mu = [], [], []
+    for r in range(N_ROUNDS):
+        il = inv(lam)
+        if r < half or r >= half + N_PARTIAL:
+            fr = r if r < half else r - N_PARTIAL
+            rc_full.append([x * il % Q for x in full[fr]])
+            lam = pow(lam, 5, Q) * step % Q
+        else:
+            kap.append(kappa[r - half] * il % Q)
+            mu.append(pow(lam, 4, Q))
+            lam = lam * step % Q
+    return rc_full, kap, mu, lam
+
+
+def hades_scaled_model(state, rc_full, kap, mu, lam_end):
+    """Exactly what the kernel does, in field arithmetic."""
+    s, half, fi, pi = list(state), N_FULL // 2, 0, 0
+    for r in range(N_ROUNDS):
+        if r < half or r >= half + N_PARTIAL:
+            t = [pow((x + rc_full[fi][i]) % Q, 5, Q) for i, x in enumerate(s)]
+            fi += 1
+        else:
+            t = s[:4] + [pow((s[4] + kap[pi]) % Q, 5, Q) * mu[pi] % Q]
+            pi += 1
+        s = [sum(SMALL_S[i][j] * t[j] for j in range(WIDTH)) * INV_2_29 % Q for i in range(WIDTH)]
+    return [x * lam_end % Q for x in s]
+
+
 # ---- subgroup test by the order-8 Tate pairing ---------------------------------------------------
 # JubJub's 2-Sylow subgroup is cyclic of order 8 (a = -1 is a square, d is not), generated by T8.
 # P is in the prime-order subgroup  <=>  the reduced Tate pairing t_8(T8, P) is trivial, i.e.
@@ -303,6 +352,23 @@ def main():
         L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in mat]
         L.append(" },")
     L.append("};")
+    rc_full, kap, mu, lam_end = scaled_hades_constants()
+    assert all(SMALL_S[i][j] * (i + j + 5) == SMALL_L and SMALL_S[i][j] < 1 << 17 for i in range(5) for j in range(5))
+    for trial in range(3):
+        st = [int.from_bytes(hashlib.sha256(b"hades-scaled-%d-%d" % (trial, i)).digest(), "little") % Q for i in range(WIDTH)]
+        assert hades_reference(st) == hades_scaled_model(st, rc_full, kap, mu, lam_end), "scaled Hades differs"
+    L.append("// Hades with the small-integer matrix S = L / (i + j + 5), L = 360360 (scaled_hades_constants())")
+    L.append("JJS_CONST uint32_t JJS_HS_MAT[5][5] = {" + ", ".join("{" + ", ".join(str(x) for x in row) + "}" for row in SMALL_S) + "};")
+    L.append("JJS_CONST uint32_t JJS_HS_RC_FULL[%d][5][9] = {" % N_FULL)
+    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in rc_full]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HS_KAPPA[%d][9] = {" % N_PARTIAL)
+    L += ["  %s," % limbs29(mont(x)) for x in kap]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HS_MU[%d][9] = {  // lambda_r^4: brings lane 4 back to the common scale" % N_PARTIAL)
+    L += ["  %s," % limbs29(mont(x)) for x in mu]
+    L.append("};")
+    L.append("JJS_CONST uint32_t JJS_HS_LAMBDA_END[9] = %s;" % limbs29(mont(lam_end)))
     L.append("JJS_CONST uint32_t JJS_MDS[5][5][9] = {")
     for i in range(WIDTH):
         L.append("  {" + ", ".join(limbs29(mont(m[i][j])) for j in range(WIDTH)) + "},")

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-phase time of the verify kernel by ablation (skip one phase, time the rest) on the bench batch.
+Usage: python jubjub_schnorr_amd/tools/phase_profile.py [scheme] [log2n]  -> one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import jubjub_schnorr_amd as jjs  # noqa: E402
+from jubjub_schnorr_amd import _ffi  # noqa: E402
+
+
+def main():
+    scheme = sys.argv[1] if len(sys.argv) > 1 else "single"
+    log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    eng = jjs.engine()
+    arrays, _ = bench.make_inputs(eng, scheme, 1 << log2n, 0)
+    call = [arrays[k] for k in bench.ARG_ORDER[scheme]]
+
+    def timed(mask):
+        _ffi.check(_ffi.lib().jjs_debug_skip_phases(mask), "skip")
+        eng.verify(scheme, *call)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); eng.verify(scheme, *call); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    full = timed(0)
+    out = {"scheme": scheme, "items": 1 << log2n, "ms_full": full,
+           "ms_without_validity": timed(1), "ms_without_challenge": timed(2), "ms_without_equations": timed(4),
+           "ms_only_loads_and_tally": timed(7)}
+    out["ms_validity"] = full - out["ms_without_validity"]
+    out["ms_challenge"] = full - out["ms_without_challenge"]
+    out["ms_equations"] = full - out["ms_without_equations"]
+    _ffi.lib().jjs_debug_skip_phases(0)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
