@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 SEED = 0x6A6A73
 N_KEYS = 4096
 ALGO_BYTES = {"single": 196, "double": 324, "vargen": 260}   # bytes in + status out per verify
+WIRE_BYTES = {"single": 132, "double": 196, "vargen": 164}   # the same through the wire entry points
 HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
 Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 ARG_ORDER = {"single": ["u", "R", "PK", "m"], "double": ["u", "R", "Rp", "PK", "PKp", "m"],
@@ -138,6 +139,8 @@ def main():
     ap.add_argument("--scheme", default="single", choices=["single", "double", "vargen"])
     ap.add_argument("--log2-items-per-gpu", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wire", action="store_true",
+                    help="feed the reference's wire formats (compressed points, decoded on the device)")
     args = ap.parse_args()
 
     import torch
@@ -161,10 +164,23 @@ def main():
     n = 1 << args.log2_items_per_gpu
     arrays, expect = make_inputs(eng, scheme, n, rank)
     call = [arrays[k] for k in ARG_ORDER[scheme]]
+    if args.wire:
+        c = {k: eng.compress(v) for k, v in arrays.items() if v.shape[1] == 64}
+        if scheme == "single":
+            wire = [torch.cat([arrays["u"], c["R"]], 1), c["PK"], arrays["m"]]
+        elif scheme == "double":
+            wire = [torch.cat([arrays["u"], c["R"], c["Rp"]], 1), torch.cat([c["PK"], c["PKp"]], 1), arrays["m"]]
+        else:
+            wire = [torch.cat([arrays["u"], c["R"]], 1), torch.cat([c["PK"], c["Gen"]], 1), arrays["m"]]
+        wire = [w.contiguous() for w in wire]
+        torch.cuda.synchronize()
     want_tally = torch.stack([(expect == k).sum() for k in range(4)]).to(torch.int64)
 
+    def run_verify():
+        return eng.verify_wire(scheme, *wire) if args.wire else eng.verify(scheme, *call)
+
     def step():
-        st, tally = eng.verify(scheme, *call)
+        st, tally = run_verify()
         allreduce_tally(tally)              # RCCL over xGMI: 4 x int64, the path's only exchange
         return st, tally
 
@@ -181,7 +197,7 @@ def main():
     for _ in range(args.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        st, tally_local = eng.verify(scheme, *call)
+        st, tally_local = run_verify()
         e1.record()
         tally = tally_local
         if dist is not None:
@@ -206,16 +222,26 @@ def main():
     if rank == 0:
         total_items = n * world * args.steps
         value = total_items / elapsed
-        achieved = ALGO_BYTES[scheme] * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        algo_bytes = WIRE_BYTES[scheme] if args.wire else ALGO_BYTES[scheme]
+        achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
+        traffic, alu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("scheme") == scheme and rec.get("items") == n:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    # the binding roofline: VALU issue.  Instruction count per launch from the
+                    # committed PMC pass, rate from THIS run's kernel time; ceiling = 1024 SIMDs issuing one
+                    # wave-instruction every 4.2 cycles (microbenchmarked cost of the cheapest multiply) at 2.4 GHz
+                    insts = rec.get("valu_wave_instr_per_launch")
+                    if insts:
+                        rate = insts / (kernel_ms * 1e-3)
+                        peak = 1024 * 2.4e9 / 4.2
+                        alu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instr/s",
+                               "frac": rate / peak, "source": rec.get("source")}
             except Exception:
-                traffic = None
+                traffic, alu = None, None
         out = {
             "metric": "Schnorr verifications/sec",
             "value": value,
@@ -231,13 +257,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"2^{args.log2_items_per_gpu} {scheme} signatures per GPU, resident in HBM "
                                    f"(BASELINE.json configs[{ {'single': 1, 'double': 2, 'vargen': 4}[scheme] }])",
-                       "scheme": scheme, "items_per_gpu": n, "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
+                       "scheme": scheme, "items_per_gpu": n, "input_format": "wire (compressed points)" if args.wire else "affine", "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
                        "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points"},
             "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "verify_kernel", "kernel_ms": kernel_ms,
-                         "note": "integer-ALU bound path (SURVEY.md 8d): see DESIGN.md for the multiply-issue roofline"},
+                         "kernel": "decode_kernel + verify_kernel" if args.wire else "verify_kernel", "kernel_ms": kernel_ms,
+                         "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6"},
+            "alu_roofline": alu,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scheme, arrays, st)

@@ -90,6 +90,25 @@ int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const vo
                           void* status, void* tally, void* stream);
 int jjs_stream_sync(void* stream);
 
+/* ---- wire formats (reference `to_bytes` / `from_bytes`), device buffers, asynchronous ------------------
+ * Points travel compressed (32 bytes: little-endian v, parity of u in bit 255) and are decoded on the
+ * device; an item with any undecodable point (v >= q, no square root, or u = 0 with the sign bit set)
+ * or a scalar out of range gets status 3, where the Rust `from_bytes` would have returned an error.
+ *   single : sig = n x 64 (u || R)        reference src/signatures.rs:104-119 ; pk = n x 32  src/keys/public.rs:83-93
+ *   double : sig = n x 96 (u || R || R')  src/signatures/double.rs:126-148    ; pk = n x 64 (pk || pk')  src/keys/public/double.rs:169-186
+ *   vargen : sig = n x 64 (u || R)        src/signatures/var_gen.rs:95-113    ; pk = n x 64 (pk || generator)  src/keys/public/var_gen.rs:54-79
+ *   m      : n x 32 (BlsScalar::to_bytes)
+ * 132 / 196 / 164 bytes per verification instead of 196 / 324 / 260. */
+int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream);
+int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream);
+int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream);
+/* JubJubAffine::from_bytes / to_bytes in bulk: in n x 32 -> affine n x 64 + ok n bytes; affine n x 64 -> n x 32 */
+int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream);
+int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream);
+
 /* ---- transcript parity (debug export): c_out = n x 32 bytes, the 250-bit challenge per item ---- */
 int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_t n, void* c_out, void* stream);
 int jjs_challenge_double_dev(const void* R, const void* R_prime, const void* PK, const void* PK_prime, const void* m,

@@ -112,6 +112,42 @@ class Engine:
                       tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}")
         return status, tally
 
+    _WIRE_WIDTHS = {"single": (64, 32, 32), "double": (96, 64, 32), "vargen": (64, 64, 32)}
+
+    def verify_wire(self, scheme: str, sig, pk, m, want_status: bool = True):
+        """Batch verify from the reference's wire formats (torch CUDA uint8 tensors): sig (n, 64|96|64) =
+        u || R [|| R'], pk (n, 32|64|64) compressed, m (n, 32).  Points are decoded on the device; an
+        undecodable item gets status 3.  Returns (status, tally), asynchronous on the current stream."""
+        import torch
+        ws, wp, wm = self._WIRE_WIDTHS[scheme]
+        n = sig.shape[0]
+        ptrs = [self._dev_ptr(sig, ws, n), self._dev_ptr(pk, wp, n), self._dev_ptr(m, wm, n)]
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=sig.device)[:n] if want_status else None
+        tally = torch.zeros(4, dtype=torch.int64, device=sig.device)
+        fn = getattr(self._lib, f"jjs_verify_{scheme}_wire_dev")
+        _ffi.check(fn(*ptrs, n, ctypes.c_void_p(status.data_ptr()) if want_status and n else None,
+                      ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}_wire_dev")
+        return status, tally
+
+    def decompress(self, enc):
+        """JubJubAffine::from_bytes in bulk: (n, 32) -> ((n, 64) affine, (n,) ok)."""
+        import torch
+        n = enc.shape[0]
+        out = torch.empty((max(n, 1), 64), dtype=torch.uint8, device=enc.device)[:n]
+        ok = torch.empty(max(n, 1), dtype=torch.uint8, device=enc.device)[:n]
+        _ffi.check(self._lib.jjs_decompress_dev(self._dev_ptr(enc, 32, n), n, ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(ok.data_ptr()), self._stream()), "jjs_decompress_dev")
+        return out, ok
+
+    def compress(self, pts):
+        """JubJubAffine::to_bytes in bulk: (n, 64) affine -> (n, 32)."""
+        import torch
+        n = pts.shape[0]
+        out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=pts.device)[:n]
+        _ffi.check(self._lib.jjs_compress_dev(self._dev_ptr(pts, 64, n), n, ctypes.c_void_p(out.data_ptr()), self._stream()),
+                   "jjs_compress_dev")
+        return out
+
     def challenge(self, scheme: str, *arrays):
         """250-bit challenge per item (torch CUDA tensors): single (R, PK, m); double (R, R', PK, PK', m);
         vargen (R, PK, Gen, m)."""

@@ -400,6 +400,31 @@ JJS_HD bool fq_eq(const fe<La, Aa>& a, const fe<1, Ab>& b) {
     return fq_is_zero(fq_sub(a, b));
 }
 
+// a^e for a public exponent given as a sliding-window schedule (tools/gen_constants.py): per step
+// `sq` squarings then a product with a^d, d in {1, 3, 5, 7}; finally `trailing` squarings.  Control
+// flow is wave-uniform (the exponent is public).
+JJS_HD fe_n fq_pow_schedule(const fe_n& a, const uint32_t (*sched)[2], int steps, int trailing) {
+    fe_n a2 = fq_sqr(a);
+    fe_n a3 = fq_mul(a2, a), a5 = fq_mul(a3, a2), a7 = fq_mul(a5, a2);
+    fe_n e = a;
+    for (int st = 0; st < steps; ++st) {
+        const uint32_t nsq = sched[st][0], dg = sched[st][1];
+        if (st != 0)
+            for (uint32_t j = 0; j < nsq; ++j) e = fq_sqr(e);
+        const fe_n m = fq_select(dg == 1, a, fq_select(dg == 3, a3, fq_select(dg == 5, a5, a7)));
+        e = (st == 0) ? m : fq_mul(e, m);
+    }
+    for (int j = 0; j < trailing; ++j) e = fq_sqr(e);
+    return e;
+}
+// x == 1 for a product output (normalised limbs, value < 2q): two possible representatives
+JJS_HD bool fq_is_one_weak(const fe_n& x) {
+    uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { d0 |= x.l[i] ^ JJS_ONE[i]; d1 |= x.l[i] ^ JJS_ONE_PLUS_Q[i]; }
+    return d0 == 0 || d1 == 0;
+}
+
 // a^e for a public exponent (wave-uniform control flow), MSB first; e as 32-bit words
 template <int A>
 JJS_HD fe_n fq_pow_public(const fe<1, A>& a, const uint32_t* e, int nbits) {

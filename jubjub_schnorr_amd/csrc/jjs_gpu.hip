@@ -13,6 +13,7 @@
 
 #include "../../include/jjs_gpu.h"
 #include "schemes.h"
+#include "decode.h"
 #include "sign_core.h"
 
 using namespace jjs;
@@ -54,6 +55,35 @@ __global__ __launch_bounds__(BLOCK) void challenge_kernel(challenge_params P) {
         fe_n d = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
         store_words(P.c_out, item, truncate250(d));
     }
+}
+
+struct decode_params {
+    uint32_t n_src, pad_;
+    fe_src src[4];        // compressed points: 32 bytes at base + i*stride + off
+    uint8_t* out[4];      // affine u || v, n x 64 each
+    uint8_t* bad;         // n bytes, set to 1 when any source of item i fails to decode (nullable)
+    uint8_t* ok;          // n bytes, 1/0 per item for source 0 (nullable; debug entry point)
+    uint64_t n;
+};
+__global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total) {
+        bool all_ok = true;
+        for (uint32_t k = 0; k < P.n_src; ++k) {
+            decoded_point d = decompress_point(load_words(P.src[k], item));
+            store_words(P.out[k], 2 * item, d.u);
+            store_words(P.out[k], 2 * item + 1, d.v);
+            all_ok = all_ok && d.ok;
+        }
+        if (P.bad && !all_ok) P.bad[item] = 1;
+        if (P.ok) P.ok[item] = all_ok ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void compress_kernel(const uint8_t* affine, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe_src s{affine, 64, 0};
+    store_words(out, i, compress_point(load_words(s, i), load_words(s, i, 32)));
 }
 
 __global__ __launch_bounds__(BLOCK) void sign_kernel(sign_params P) {
@@ -104,6 +134,8 @@ struct engine {
     unsigned long long* tally = nullptr;
     int grid_verify = 0, grid_sign = 0;
     size_t ws_lanes = 0;
+    uint8_t* wire = nullptr;       // decoded points (4 x n x 64) + flags (n) for the *_wire entry points
+    size_t wire_items = 0;
     std::mutex mu;
     char err[512] = "";
 };
@@ -219,6 +251,8 @@ void jjs_shutdown(void) {
     if (!g.ready) return;
     (void)hipStreamSynchronize(g.stream);
     (void)hipFree(g.workspace); (void)hipFree(g.comb_g); (void)hipFree(g.comb_gn); (void)hipFree(g.tag); (void)hipFree(g.tally);
+    if (g.wire) (void)hipFree(g.wire);
+    g.wire = nullptr; g.wire_items = 0;
     (void)hipStreamDestroy(g.stream);
     g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
     g.ready = false;
@@ -313,6 +347,115 @@ int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, con
                                               (uint8_t*)dm.d, n, o), dst.d, g.tally, g.stream)))
         return rc;
     return finish_host(dst, status, tally, n);
+}
+
+// ---- wire formats: on-device decoding, then the same verify kernel -----------------------------------
+static int ensure_wire(size_t n) {
+    if (n <= g.wire_items) return JJS_OK;
+    if (g.wire) {
+        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old buffer
+        HIP_TRY(hipFree(g.wire));
+        g.wire = nullptr; g.wire_items = 0;
+    }
+    size_t cap = n < 4096 ? 4096 : n;
+    HIP_TRY(hipMalloc(&g.wire, cap * (4 * 64 + 16)));
+    g.wire_items = cap;
+    return JJS_OK;
+}
+static uint8_t* wire_pts(int k) { return g.wire + (size_t)k * g.wire_items * 64; }
+static uint8_t* wire_bad() { return g.wire + (size_t)4 * g.wire_items * 64; }
+
+static int launch_decode(decode_params D, hipStream_t s) {
+    size_t blocks = (D.n + BLOCK - 1) / BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, D);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+
+int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
+    decode_params D{};
+    D.n_src = 2; D.n = n; D.bad = wire_bad();
+    D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
+    D.src[1] = fe_src{(const uint8_t*)pk, 32, 0};   D.out[1] = wire_pts(1);      // PK
+    if (int rc = launch_decode(D, s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g.comb_g, o);
+    P.u = fe_src{(const uint8_t*)sig, 64, 0};
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
+    decode_params D{};
+    D.n_src = 4; D.n = n; D.bad = wire_bad();
+    D.src[0] = fe_src{(const uint8_t*)sig, 96, 32}; D.out[0] = wire_pts(0);      // R
+    D.src[1] = fe_src{(const uint8_t*)sig, 96, 64}; D.out[1] = wire_pts(1);      // R'
+    D.src[2] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[2] = wire_pts(2);      // PK
+    D.src[3] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[3] = wire_pts(3);      // PK'
+    if (int rc = launch_decode(D, s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    verify_params P = params_double((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3),
+                                    (const uint8_t*)m, n, g.tag, g.comb_g, g.comb_gn, o);
+    P.u = fe_src{(const uint8_t*)sig, 96, 0};
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                               void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
+    decode_params D{};
+    D.n_src = 3; D.n = n; D.bad = wire_bad();
+    D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
+    D.src[1] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[1] = wire_pts(1);      // PK
+    D.src[2] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[2] = wire_pts(2);      // generator
+    if (int rc = launch_decode(D, s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
+    P.u = fe_src{(const uint8_t*)sig, 64, 0};
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!all_ok(in, affine_out) || !ok_out) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    decode_params D{};
+    D.n_src = 1; D.n = n; D.ok = (uint8_t*)ok_out;
+    D.src[0] = fe_src{(const uint8_t*)in, 32, 0}; D.out[0] = (uint8_t*)affine_out;
+    return launch_decode(D, (hipStream_t)stream);
+}
+int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!all_ok(affine, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipLaunchKernelGGL(compress_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t*)affine, (uint64_t)n, (uint8_t*)out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
 }
 
 // ---- challenge export ---------------------------------------------------------------------------

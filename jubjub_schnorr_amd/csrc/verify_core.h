@@ -49,6 +49,7 @@ struct verify_params {
     uint8_t* status;                 // n bytes, or nullptr
     unsigned long long* tally;       // 4 counters, or nullptr
     uint8_t* c_out;                  // n x 32 bytes challenge (debug export), or nullptr
+    const uint8_t* pre_malformed;    // n bytes from the wire decoder (non-zero: an encoding was rejected), or nullptr
     uint32_t* workspace;             // WS_WORDS_PER_LANE words per resident lane
 };
 
@@ -388,18 +389,7 @@ JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
     fe_n y2 = fq_sqr(y);
     fe_n y7 = fq_mul(fq_mul(fq_sqr(y2), y2), y);
     fe_n g = fq_mul(a, y7);
-    // g^((q-1)/8) by a public sliding-window schedule (width 3: g, g^3, g^5, g^7 in registers)
-    fe_n g2 = fq_sqr(g);
-    fe_n g3 = fq_mul(g2, g), g5 = fq_mul(g3, g2), g7 = fq_mul(g5, g2);
-    fe_n e = fe_n_one();
-    for (int st = 0; st < JJS_PAIR_SW_STEPS; ++st) {
-        const uint32_t nsq = JJS_PAIR_SW[st][0], dg = JJS_PAIR_SW[st][1];
-        if (st != 0)
-            for (uint32_t j = 0; j < nsq; ++j) e = fq_sqr(e);
-        const fe_n m = fq_select(dg == 1, g, fq_select(dg == 3, g3, fq_select(dg == 5, g5, g7)));
-        e = (st == 0) ? m : fq_mul(e, m);
-    }
-    for (int j = 0; j < JJS_PAIR_SW_TRAILING; ++j) e = fq_sqr(e);
+    fe_n e = fq_pow_schedule(g, JJS_PAIR_SW, JJS_PAIR_SW_STEPS, JJS_PAIR_SW_TRAILING);
     return fq_eq(e, fq_one());
 }
 
@@ -460,7 +450,8 @@ JJS_HD words8 select_words(bool c, const words8& a, const words8& b) {
 //  * Per-item generator: Straus over two per-lane tables (PK, Gen), 252 shared doublings, compared
 //    with R projectively.
 // Both cases run the same window loop (one copy of the doubling and addition code in the kernel).
-JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const words8& u, const words8& c) {
+JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const words8& u, const words8& c,
+                           const half_scalars& h) {
     const bool fixed = (E.comb != nullptr);
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {                       // table 0: PK; table 1: R (fixed) or Gen
@@ -472,7 +463,6 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
     int top;
     bool flip1;
     if (fixed) {
-        const half_scalars h = half_size_scalars(c);
         words8 r2;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
@@ -524,6 +514,7 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
     bool malformed = !words_lt(u, JJS_FR_WORDS);
+    if (P.pre_malformed) malformed = malformed || P.pre_malformed[item] != 0;
     for (uint32_t e = 0; e < P.n_hash; ++e) malformed = malformed || !words_lt(load_words(P.hash_in[e], item), JJS_Q_WORDS);
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
@@ -543,13 +534,16 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
 
     // 4. equations
     bool eq_ok = true;
-    for (uint32_t k = 0; k < ((P.skip_phases & 4u) ? 0u : P.n_eq); ++k) eq_ok = check_equation(P.eq[k], item, ws, u, c) && eq_ok;
+    const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
+    half_scalars h{};
+    if (n_eq && P.eq[0].comb) h = half_size_scalars(c);     // shared by both equations of the double scheme
+    for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, c, h) && eq_ok;
 
     return malformed ? ST_MALFORMED : (!valid ? ST_INVALID_POINT : (!eq_ok ? ST_INVALID_SIGNATURE : ST_OK));
 }
 
 // ---- fixed-base comb table: entry (i, b) = b * 256^i * Base as an affine cached addend ------------
-JJS_HD fe_n fq_inverse(const fe_n& a) { return fq_pow_public(a, JJS_QM2_WORDS, 255); }
+JJS_HD fe_n fq_inverse(const fe_n& a) { return fq_pow_schedule(a, JJS_INV_SW, JJS_INV_SW_STEPS, JJS_INV_SW_TRAILING); }
 
 JJS_HD void build_comb_entry(uint32_t* table, const uint32_t (*base)[9], int i, int b) {
     fe_n bu = fq_as<1, 2>(fe_from_const<1, 1>(base[0])), bv = fq_as<1, 2>(fe_from_const<1, 1>(base[1]));

@@ -321,11 +321,19 @@ def main():
     L.append("JJS_CONST uint32_t JJS_PAIR_NEG_L2[9] = %s;" % limbs29(mont(pc["NEG_L2"])))
     L.append("JJS_CONST uint32_t JJS_PAIR_B[9] = %s;" % limbs29(mont(pc["B"])))
     L.append("JJS_CONST uint32_t JJS_PAIR_EXP_WORDS[8] = %s;  // (q - 1) / 8" % words32((Q - 1) // 8))
-    steps, trailing = sliding_window_schedule((Q - 1) // 8, 3)
-    L.append("// (q - 1) / 8 as a left-to-right sliding-window (width 3) schedule: {squarings, odd digit} per step")
-    L.append("#define JJS_PAIR_SW_STEPS %d" % len(steps))
-    L.append("#define JJS_PAIR_SW_TRAILING %d" % trailing)
-    L.append("JJS_CONST uint32_t JJS_PAIR_SW[JJS_PAIR_SW_STEPS][2] = {" + ", ".join("{%d, %d}" % st for st in steps) + "};")
+    L.append("// public exponents as left-to-right sliding-window (width 3) schedules: {squarings, odd digit} per step,")
+    L.append("// then TRAILING squarings (fq_pow_schedule)")
+    t_odd = (Q - 1) >> 32
+    assert (Q - 1) == t_odd << 32 and t_odd & 1
+    for name, e in (("PAIR", (Q - 1) // 8), ("INV", Q - 2), ("SQRT", (t_odd - 1) // 2)):
+        steps, trailing = sliding_window_schedule(e, 3)
+        L.append("#define JJS_%s_SW_STEPS %d  // exponent 0x%x" % (name, len(steps), e))
+        L.append("#define JJS_%s_SW_TRAILING %d" % (name, trailing))
+        L.append("JJS_CONST uint32_t JJS_%s_SW[JJS_%s_SW_STEPS][2] = {" % (name, name) + ", ".join("{%d, %d}" % st for st in steps) + "};")
+    zeta = pow(7, t_odd, Q)
+    assert pow(zeta, 1 << 31, Q) == Q - 1, "7 must be a non-residue"
+    L.append("JJS_CONST uint32_t JJS_ROOT_OF_UNITY[9] = %s;  // 7^((q-1)/2^32): generator of the 2^32-torsion of Fq*" % limbs29(mont(zeta)))
+    L.append("JJS_CONST uint32_t JJS_ONE_PLUS_Q[9] = %s;  // the other representative of 1 below 2q" % limbs29(MONT + Q))
     L.append("JJS_CONST uint32_t JJS_RC[%d][9] = {" % len(rc))
     L += ["  %s," % limbs29(mont(c)) for c in rc]
     L.append("};")

@@ -200,6 +200,8 @@ def decompress(b: bytes):
     if u is None:
         return None
     if (u & 1) != sign:
+        if u == 0:
+            return None  # u = 0 with the sign bit set: unpinned by the reference's tests; rejected (ZIP 216)
         u = (-u) % Q
     return (u, v)
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #include "schemes.h"
+#include "decode.h"
 
 using namespace jjs;
 
@@ -107,6 +108,17 @@ int jjs_host_half_size(const uint8_t* c, size_t n, uint8_t* out) {
         half_scalars h = half_size_scalars(w);
         memcpy(out + 33 * i, h.a.w, 16); memcpy(out + 33 * i + 16, h.b.w, 16);
         out[33 * i + 32] = h.b_neg ? 1 : 0;
+    }
+    return 0;
+}
+// compressed (n x 32) -> affine (n x 64) + ok byte
+int jjs_host_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+    for (size_t i = 0; i < n; ++i) {
+        words8 w;
+        memcpy(w.w, in + 32 * i, 32);
+        decoded_point d = decompress_point(w);
+        memcpy(out + 64 * i, d.u.w, 32); memcpy(out + 64 * i + 32, d.v.w, 32);
+        ok[i] = d.ok ? 1 : 0;
     }
     return 0;
 }

@@ -89,3 +89,8 @@ def verify(scheme, b, want_c=False):
 def half_size(c):
     c = _c(c); out = np.empty((len(c), 33), np.uint8)
     load().jjs_host_half_size(_p(c), ctypes.c_size_t(len(c)), _p(out)); return out
+
+
+def decompress(c):
+    c = _c(c); out = np.empty((len(c), 64), np.uint8); ok = np.empty(len(c), np.uint8)
+    load().jjs_host_decompress(_p(c), ctypes.c_size_t(len(c)), _p(out), _p(ok)); return out, ok

@@ -214,3 +214,78 @@ def test_full_size_properties(eng, scheme, log2n):
     sel = torch.from_numpy(np.random.default_rng(5).choice(n, 2048, replace=False)).cuda()
     sample = {k: host(v[sel]) for k, v in arrs.items()}
     assert host(st[sel]).tolist() == oracle_verify(scheme, sample).tolist()
+
+
+# ---- wire formats ---------------------------------------------------------------------
+def test_decompress_and_compress(eng):
+    from test_hostbuild import wire_point_cases
+    enc = wire_point_cases(np.random.default_rng(41), n_random=256)
+    arr = np.frombuffer(b"".join(enc), np.uint8).reshape(-1, 32)
+    out, ok = eng.decompress(dev(arr))
+    out, ok = host(out), host(ok)
+    good = []
+    for i, e in enumerate(enc):
+        want = o.decompress(e)
+        assert bool(ok[i]) == (want is not None), i
+        assert out[i].tobytes() == ((o.le32(want[0]) + o.le32(want[1])) if want else (o.le32(0) + o.le32(1))), i
+        if want:
+            good.append(i)
+    back = host(eng.compress(dev(out[good])))
+    assert [r.tobytes() for r in back] == [enc[i] for i in good]
+
+
+def to_wire(scheme, b):
+    comp = lambda a: np.stack([np.frombuffer(o.compress((int.from_bytes(r[:32].tobytes(), "little"),  # noqa: E731
+                                                         int.from_bytes(r[32:].tobytes(), "little"))), np.uint8) for r in a])
+    if scheme == "single":
+        return np.concatenate([b["u"], comp(b["R"])], 1), comp(b["PK"]), b["m"]
+    if scheme == "double":
+        return np.concatenate([b["u"], comp(b["R"]), comp(b["Rp"])], 1), np.concatenate([comp(b["PK"]), comp(b["PKp"])], 1), b["m"]
+    return np.concatenate([b["u"], comp(b["R"])], 1), np.concatenate([comp(b["PK"]), comp(b["Gen"])], 1), b["m"]
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+@pytest.mark.parametrize("n", [1, 65, 600])
+def test_verify_wire(eng, scheme, n):
+    """Wire entry points: same statuses as the affine path on decodable items; undecodable -> 3."""
+    b = make_batch(scheme, n, seed=300 + n, n_keys=8)
+    want = oracle_verify(scheme, b).copy()
+    sig, pk, m = to_wire(scheme, b)
+    # the mixed-order / small-order points of make_batch are on the curve, so they survive compression
+    rng = np.random.default_rng(n)
+    bad_rows = rng.choice(n, size=max(1, n // 10), replace=False)
+    nonres = next(o.le32(v) for v in range(2, 100) if o.decompress(o.le32(v)) is None)
+    for j, i in enumerate(bad_rows):
+        kind = j % 3
+        if kind == 0:
+            sig[i, 32:64] = np.frombuffer(nonres, np.uint8)                 # R: no square root
+        elif kind == 1:
+            pk[i, :32] = np.frombuffer(o.le32(o.Q), np.uint8)                # PK: v = q
+        else:
+            z = bytearray(o.compress(o.IDENTITY)); z[31] |= 0x80             # PK: u = 0 with sign bit
+            pk[i, :32] = np.frombuffer(bytes(z), np.uint8)
+        want[i] = 3
+    st, tally = eng.verify_wire(scheme, dev(sig), dev(pk), dev(m))
+    assert host(st).tolist() == want.tolist()
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+
+
+def test_verify_wire_golden_serde_bytes(eng, reference_kat):
+    """The reference's own serialised signature / key bytes (tests/serde.rs, seed 2321) straight into the
+    wire entry points."""
+    v = reference_kat["serde_base58"]
+    rng = o.StdRng(v["seed"]); rng.random_fr(); m = o.le32(rng.random_fq())
+    A = lambda x, w: dev(np.frombuffer(x, np.uint8).reshape(1, w))  # noqa: E731
+    st, _ = eng.verify_wire("single", A(o.b58decode(v["serde_signature"]), 64), A(o.b58decode(v["serde_public_key"]), 32), A(m, 32))
+    assert host(st).tolist() == [0]
+    st, _ = eng.verify_wire("double", A(o.b58decode(v["serde_signature_double"]), 96),
+                            A(o.b58decode(v["serde_public_key_double"]), 64), A(m, 32))
+    assert host(st).tolist() == [0]
+    rng = o.StdRng(v["seed"]); rng.random_fr(); rng.random_fr(); m = o.le32(rng.random_fq())
+    st, _ = eng.verify_wire("vargen", A(o.b58decode(v["serde_signature_var_gen"]), 64),
+                            A(o.b58decode(v["serde_public_key_var_gen"]), 64), A(m, 32))
+    assert host(st).tolist() == [0]
+    k = reference_kat["multisig_kat"]
+    st, _ = eng.verify_wire("single", A(bytes.fromhex(k["signature"]), 64), A(bytes.fromhex(k["aggregate_public_key"]), 32),
+                            A(o.le32(k["message"]), 32))
+    assert host(st).tolist() == [0]

@@ -100,3 +100,45 @@ def test_half_size_scalars():
             b = -b
         assert 0 <= a < 1 << 126 and 0 < abs(b) < 1 << 126, (i, a, b)
         assert (a - b * ci) % o.R_ORDER == 0, i
+
+
+def wire_point_cases(rng, n_random=64):
+    """Compressed encodings covering every decode branch, with the oracle's answer."""
+    enc = []
+    for _ in range(n_random):
+        p = o.mul(o.G, int.from_bytes(rng.bytes(31), "little") + 1)
+        enc.append(o.compress(p))
+    t8 = torsion_generator()
+    enc += [o.compress(o.mul(t8, k)) for k in range(8)]              # small-order points decode fine
+    enc += [o.compress(o.IDENTITY), o.compress(o.ORDER2)]
+    ident_bad = bytearray(o.compress(o.IDENTITY)); ident_bad[31] |= 0x80   # u = 0, sign bit set
+    o2_bad = bytearray(o.compress(o.ORDER2)); o2_bad[31] |= 0x80
+    enc += [bytes(ident_bad), bytes(o2_bad)]
+    enc.append(o.le32(o.Q))                                              # v = q (non canonical)
+    enc.append(bytes([0xFF] * 31 + [0x7F]))                              # v = 2^255 - 1
+    v = 2
+    while len(enc) < n_random + 24:                                      # v with no square root
+        b = o.le32(v)
+        if o.decompress(b) is None:
+            enc.append(b)
+        v += 1
+    for i in range(n_random // 2):                                      # sign bit flipped -> the negated point
+        b = bytearray(enc[i]); b[31] ^= 0x80; enc.append(bytes(b))
+    return enc
+
+
+def test_decompress_matches_oracle():
+    rng = np.random.default_rng(31)
+    enc = wire_point_cases(rng)
+    arr = np.frombuffer(b"".join(enc), np.uint8).reshape(-1, 32)
+    out, ok = hl.decompress(arr)
+    n_fail = 0
+    for i, e in enumerate(enc):
+        want = o.decompress(e)
+        assert bool(ok[i]) == (want is not None), i
+        if want is None:
+            n_fail += 1
+            assert out[i].tobytes() == o.le32(0) + o.le32(1)
+        else:
+            assert out[i].tobytes() == o.le32(want[0]) + o.le32(want[1]), i
+    assert n_fail >= 10
