@@ -56,6 +56,15 @@ class Engine:
     """One engine per process, bound to the current HIP device (one process per GPU)."""
 
     def __init__(self):
+        # When PyTorch shares the process, let it bring up the HIP runtime first: torch ships its own
+        # libamdhip64 and fails with "No HIP GPUs are available" if another copy initialised the device
+        # before it (observed on ROCm 7.2 / torch 2.10).
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         self._lib = _ffi.lib()
         _ffi.check(self._lib.jjs_init(0), "jjs_init")
 

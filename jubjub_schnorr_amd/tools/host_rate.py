@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the blocking host-buffer entry point (never bench.py's `value`): numpy arrays in,
+status out, including hipMalloc/H2D/D2H inside jjs_verify_single.  One JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import jubjub_schnorr_amd as jjs  # noqa: E402
+
+
+def main():
+    log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    eng = jjs.engine()
+    arrays, expect = bench.make_inputs(eng, "single", 1 << log2n, 0)
+    host = [arrays[k].cpu().numpy() for k in bench.ARG_ORDER["single"]]
+    eng.verify("single", *host)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st, tally = eng.verify("single", *host)
+        best = min(best, time.perf_counter() - t0)
+    assert (st == expect.cpu().numpy()).all()
+    print(json.dumps({"what": "jjs_verify_single host buffers (pageable), PCIe inclusive", "items": 1 << log2n,
+                      "seconds": best, "verifications_per_s": (1 << log2n) / best}))
+
+
+if __name__ == "__main__":
+    main()

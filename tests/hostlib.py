@@ -26,7 +26,9 @@ def load():
     if _lib is not None:
         return _lib
     if _stale():
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas",
+        # JJS_HOST_SANITIZE=1 python -m pytest tests/test_hostbuild.py  -> the same tests under UBSan
+        san = ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=undefined"] if os.environ.get("JJS_HOST_SANITIZE") else ["-O2"]
+        subprocess.check_call(["g++", *san, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas",
                                "-I" + CSRC, "-o", LIB, SRC])
     _lib = ctypes.CDLL(LIB)
     return _lib
