@@ -55,9 +55,9 @@ JJS_HD void hades_permute(hades_state& st) {
 // transcript element e) and squeezes one element.  The sponge is processed in rate-4 blocks so that
 // the permutation has a single call site and no input has to stay live across a permutation.
 template <typename Fetch>
-JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch) {
+JJS_HD fe_n poseidon_digest_tagged(int n_inputs, const fe_n& tag, Fetch fetch) {
     hades_state st;
-    st.s[0] = fq_as<1, 2>(fe_from_const<1, 1>(JJS_SPONGE_TAG[n_inputs]));
+    st.s[0] = tag;
 #pragma unroll
     for (int i = 1; i < 5; ++i) st.s[i] = fq_as<1, 2>(fq_zero());
     const int n_blocks = (n_inputs + 3) >> 2;
@@ -70,6 +70,12 @@ JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch) {
         hades_permute(st);
     }
     return st.s[1];
+}
+
+// transcripts of up to JJS_MAX_HASH_INPUTS elements: the SAFE tag comes from the constant table
+template <typename Fetch>
+JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch) {
+    return poseidon_digest_tagged(n_inputs, fq_as<1, 2>(fe_from_const<1, 1>(JJS_SPONGE_TAG[n_inputs])), fetch);
 }
 
 // digest -> canonical words, low 250 bits (JubJubScalar)

@@ -15,6 +15,8 @@
 #include "schemes.h"
 #include "decode.h"
 #include "sign_core.h"
+#include "multisig_core.h"
+#include "jjs_sponge_tags_long.inc"
 
 using namespace jjs;
 
@@ -93,6 +95,25 @@ __global__ __launch_bounds__(BLOCK) void sign_kernel(sign_params P) {
     for (uint64_t item = gtid; item < P.n; item += total) sign_item(P, item, ws);
 }
 
+// multisig passes: 0 map, 1 delinearisation, 2 aggregate key + a, 3 commitments, 4 RSa + c + u, 5 shares
+__global__ __launch_bounds__(BLOCK) void msig_kernel(msig_params P, int pass) {
+    const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    uint32_t* ws = P.lane_ws + gtid * WS_WORDS_PER_LANE;
+    const bool per_transcript = (pass == 0 || pass == 2 || pass == 4);
+    const uint64_t count = per_transcript ? P.n_transcripts : P.n_total;
+    for (uint64_t i = gtid; i < count; i += total) {
+        switch (pass) {
+        case 0: msig_map_item(P, (uint32_t)i); break;
+        case 1: msig_delin_item(P, i, ws); break;
+        case 2: msig_agg_item(P, (uint32_t)i); break;
+        case 3: msig_commit_item(P, i, ws); break;
+        case 4: msig_final_item(P, (uint32_t)i); break;
+        default: msig_share_item(P, i, ws); break;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void comb_kernel(uint32_t* table, int which) {
     int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= COMB_WINDOWS * COMB_ENTRIES) return;
@@ -134,6 +155,10 @@ struct engine {
     unsigned long long* tally = nullptr;
     int grid_verify = 0, grid_sign = 0;
     size_t ws_lanes = 0;
+    uint32_t* tags_long = nullptr; // SAFE tags for long transcripts (multisig)
+    uint8_t* msig = nullptr;       // multisig scratch
+    size_t msig_items = 0, msig_transcripts = 0;
+    int grid_msig = 0;
     uint8_t* wire = nullptr;       // decoded points (4 x n x 64) + flags (n) for the *_wire entry points
     size_t wire_items = 0;
     std::mutex mu;
@@ -225,17 +250,24 @@ int jjs_init(int device_count) {
     int per_cu_v = 0, per_cu_s = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
+    int per_cu_m = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_m, msig_kernel, BLOCK, 0));
+    if (per_cu_m < 1) per_cu_m = 1;
+    g.grid_msig = prop.multiProcessorCount * per_cu_m;
     if (per_cu_v < 1) per_cu_v = 1;
     if (per_cu_s < 1) per_cu_s = 1;
     g.grid_verify = prop.multiProcessorCount * per_cu_v;
     g.grid_sign = prop.multiProcessorCount * per_cu_s;
     int lanes_blocks = g.grid_verify > g.grid_sign ? g.grid_verify : g.grid_sign;
+    if (g.grid_msig > lanes_blocks) lanes_blocks = g.grid_msig;
     g.ws_lanes = (size_t)lanes_blocks * BLOCK;
     HIP_TRY(hipMalloc(&g.workspace, g.ws_lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&g.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&g.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&g.tag, 32));
     HIP_TRY(hipMalloc(&g.tally, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&g.tags_long, sizeof(JJS_SPONGE_TAG_LONG)));
+    HIP_TRY(hipMemcpyAsync(g.tags_long, JJS_SPONGE_TAG_LONG, sizeof(JJS_SPONGE_TAG_LONG), hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(g.tag, JJS_DOUBLE_TAG_WORDS, 32, hipMemcpyHostToDevice, g.stream));
     const int blocks = (COMB_WINDOWS * COMB_ENTRIES + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, g.stream, g.comb_g, 0);
@@ -253,6 +285,9 @@ void jjs_shutdown(void) {
     (void)hipFree(g.workspace); (void)hipFree(g.comb_g); (void)hipFree(g.comb_gn); (void)hipFree(g.tag); (void)hipFree(g.tally);
     if (g.wire) (void)hipFree(g.wire);
     g.wire = nullptr; g.wire_items = 0;
+    if (g.msig) (void)hipFree(g.msig);
+    g.msig = nullptr; g.msig_items = g.msig_transcripts = 0;
+    (void)hipFree(g.tags_long); g.tags_long = nullptr;
     (void)hipStreamDestroy(g.stream);
     g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
     g.ready = false;
@@ -454,6 +489,51 @@ int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
     if (!all_ok(affine, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     hipLaunchKernelGGL(compress_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t*)affine, (uint64_t)n, (uint8_t*)out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+
+// ---- multisig: batch verify_share / combine -------------------------------------------
+int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const void* S, const void* m,
+                             const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* agg_pk,
+                             void* sig_u, void* sig_R, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n_transcripts == 0) return JJS_OK;
+    if (!offsets_host || offsets_host[0] != 0) return fail(JJS_ERR_ARG, "offsets must start at 0");
+    for (size_t t = 0; t < n_transcripts; ++t) {
+        if (offsets_host[t + 1] <= offsets_host[t] || offsets_host[t + 1] - offsets_host[t] > JJS_MSIG_MAX_PARTICIPANTS)
+            return fail(JJS_ERR_ARG, "transcript %zu: participant count must be in [1, %d] (InvalidMultisigTranscript)", t,
+                        JJS_MSIG_MAX_PARTICIPANTS);
+    }
+    const size_t n = offsets_host[n_transcripts];
+    if (!all_ok(z, PK, R, S, m, agg_pk, sig_u, sig_R) || !share_status) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n > g.msig_items || n_transcripts > g.msig_transcripts) {
+        if (g.msig) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g.msig)); g.msig = nullptr; }
+        size_t ci = n < 4096 ? 4096 : n, ct = n_transcripts < 1024 ? 1024 : n_transcripts;
+        HIP_TRY(hipMalloc(&g.msig, ci * 4 * (1 + 8 + 2 * EXT_WORDS) + ct * 4 * (16 + 1) + 64));
+        g.msig_items = ci; g.msig_transcripts = ct;
+    }
+    msig_params P{};
+    P.z = (const uint8_t*)z; P.PK = (const uint8_t*)PK; P.R = (const uint8_t*)R; P.S = (const uint8_t*)S; P.m = (const uint8_t*)m;
+    P.n_transcripts = (uint32_t)n_transcripts; P.n_total = n;
+    P.share_status = (uint8_t*)share_status; P.agg_pk = (uint8_t*)agg_pk; P.sig_u = (uint8_t*)sig_u; P.sig_R = (uint8_t*)sig_R;
+    uint32_t* w = (uint32_t*)g.msig;
+    P.tr_of = w; w += g.msig_items;
+    P.d_words = w; w += 8 * g.msig_items;
+    P.dpk = w; w += EXT_WORDS * g.msig_items;
+    P.e_pt = w; w += EXT_WORDS * g.msig_items;
+    P.a_words = w; w += 8 * g.msig_transcripts;
+    P.c_words = w; w += 8 * g.msig_transcripts;
+    uint32_t* d_off = w;
+    P.offsets = d_off;
+    P.tags = g.tags_long; P.comb_g = g.comb_g; P.lane_ws = g.workspace;
+    HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    for (int pass = 0; pass < 6; ++pass) {
+        const size_t count = (pass == 0 || pass == 2 || pass == 4) ? n_transcripts : n;
+        hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g.grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
+    }
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }

@@ -32,8 +32,8 @@ JJS_HD ext_pt comb_mul(const uint32_t* comb, const words8& k) {
     }
     return acc;
 }
-// k * P for the table of P built by build_point_table; k < 2^252
-JJS_HD ext_pt table_mul(const uint32_t* tab, const words8& k) {
+// k * P for the table of P built by build_point_table; k < 2^252.  T is only valid when final_t is set.
+JJS_HD ext_pt table_mul(const uint32_t* tab, const words8& k, bool final_t = false) {
     const words8 sk = recode_signed4(k);
     ext_pt acc = ext_identity();
     for (int w = 63; w >= 0; --w) {
@@ -43,7 +43,7 @@ JJS_HD ext_pt table_mul(const uint32_t* tab, const words8& k) {
             acc = ext_double(acc, false);
             acc = ext_double(acc, true);
         }
-        acc = add_window(acc, tab, sk, w, false);
+        acc = add_window(acc, tab, sk, w, final_t && w == 0);
     }
     return acc;
 }

@@ -384,6 +384,19 @@ def main():
     with open(OUT, "w") as f:
         f.write("\n".join(L) + "\n")
     print("wrote", OUT)
+    # SAFE tags for long transcripts (multisig: 2 + 2n and 3 + 4n inputs, n <= 256 participants): host table,
+    # uploaded to the device at jjs_init
+    T = ["// GENERATED by jubjub_schnorr_amd/tools/gen_constants.py -- do not edit.",
+         "#define JJS_MSIG_MAX_PARTICIPANTS 256",
+         "#define JJS_LONG_TAGS %d" % (3 + 4 * 256 + 1),
+         "static const uint32_t JJS_SPONGE_TAG_LONG[JJS_LONG_TAGS][9] = {"]
+    for n in range(3 + 4 * 256 + 1):
+        T.append("  %s," % limbs29(mont(sponge_tag(n)) if n else 0))
+    T.append("};")
+    out2 = os.path.join(os.path.dirname(OUT), "jjs_sponge_tags_long.inc")
+    with open(out2, "w") as f:
+        f.write("\n".join(T) + "\n")
+    print("wrote", out2)
 
 
 if __name__ == "__main__":

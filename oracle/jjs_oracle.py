@@ -473,6 +473,31 @@ def multisig_transcript(pks, Rs, Ss, m: int):
     return ds, agg, a, rsa, c
 
 
+def multisig_sign_share(sk: int, r: int, s: int, pks, Rs, Ss, m: int) -> int:
+    """sign_round_2 (src/multisig.rs:213-257) without the structural checks: z = r + s*a - c*d_i*sk."""
+    ds, _, a, _, c = multisig_transcript(pks, Rs, Ss, m)
+    i = pks.index(mul(G, sk))
+    return (r + s * a - c * ds[i] * sk) % R_ORDER
+
+
+def multisig_verify_share(z: int, index: int, pks, Rs, Ss, m: int) -> bool:
+    """verify_share (src/multisig.rs:284-309, 366-387): z*G + (c*d_i)*PK_i == R_i + a*S_i."""
+    ds, _, a, _, c = multisig_transcript(pks, Rs, Ss, m)
+    lhs = add(mul(G, z), mul(pks[index], c * ds[index] % R_ORDER))
+    rhs = add(Rs[index], mul(Ss[index], a))
+    return lhs == rhs
+
+
+def multisig_combine(zs, pks, Rs, Ss, m: int):
+    """combine (src/multisig.rs:326-360): (None, first bad index) or ((u, RSa), None)."""
+    ds, _, a, rsa, c = multisig_transcript(pks, Rs, Ss, m)
+    for i, z in enumerate(zs):
+        lhs = add(mul(G, z), mul(pks[i], c * ds[i] % R_ORDER))
+        if lhs != add(Rs[i], mul(Ss[i], a)):
+            return None, i
+    return (sum(zs) % R_ORDER, rsa), None
+
+
 # ----------------------------------------------------------------------------
 # base58 (bitcoin alphabet), for tests/serde.rs vectors
 # ----------------------------------------------------------------------------

@@ -184,3 +184,24 @@ def edge_cases(scheme: str):
     variant(u=np.full(32, 0xFF, np.uint8))
     b = {k: np.stack([it[k] for it in items]) for k in base}
     return b
+
+
+def make_multisig_batch(n_transcripts: int, seed: int = 5, max_n: int = 5, corrupt: bool = True):
+    """Random multisig transcripts through the Python oracle.  Returns arrays, offsets and, per
+    transcript, the oracle's (aggregate key, a, RSa, c); expected share statuses (0 / 4)."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda mod: int.from_bytes(rng.bytes(40), "little") % (mod - 1) + 1  # noqa: E731
+    z, PK, R, S, m, offs, want, info = [], [], [], [], [], [0], [], []
+    for t in range(n_transcripts):
+        n = int(rng.integers(1, max_n + 1))
+        sks = [rnd(o.R_ORDER) for _ in range(n)]; rs = [rnd(o.R_ORDER) for _ in range(n)]; ss = [rnd(o.R_ORDER) for _ in range(n)]
+        pks = [o.mul(o.G, x) for x in sks]; Rs = [o.mul(o.G, x) for x in rs]; Ss = [o.mul(o.G, x) for x in ss]
+        msg = rnd(o.Q)
+        ds, agg, a, rsa, c = o.multisig_transcript(pks, Rs, Ss, msg)
+        zs = [(rs[i] + ss[i] * a - c * ds[i] * sks[i]) % o.R_ORDER for i in range(n)]
+        st = [0] * n
+        if corrupt and t % 3 == 1:
+            j = int(rng.integers(0, n)); zs[j] = (zs[j] + 1) % o.R_ORDER; st[j] = 4
+        z += zs; PK += pks; R += Rs; S += Ss; m.append(msg); offs.append(offs[-1] + n); want += st
+        info.append((agg, sum(zs) % o.R_ORDER, rsa))
+    return (fe_arr(z), pt_arr(PK), pt_arr(R), pt_arr(S), fe_arr(m), np.array(offs, np.uint32), np.array(want, np.uint8), info)

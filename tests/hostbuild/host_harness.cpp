@@ -6,6 +6,8 @@
 #include <vector>
 #include "schemes.h"
 #include "decode.h"
+#include "multisig_core.h"
+#include "jjs_sponge_tags_long.inc"
 
 using namespace jjs;
 
@@ -120,6 +122,25 @@ int jjs_host_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) 
         memcpy(out + 64 * i, d.u.w, 32); memcpy(out + 64 * i + 32, d.v.w, 32);
         ok[i] = d.ok ? 1 : 0;
     }
+    return 0;
+}
+int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, const uint8_t* S, const uint8_t* m,
+                      const uint32_t* offsets, size_t B, uint8_t* status, uint8_t* agg_pk, uint8_t* sig_u, uint8_t* sig_R) {
+    ensure_tables();
+    const size_t n = offsets[B];
+    std::vector<uint32_t> tr(n), d(8 * n), dpk(EXT_WORDS * n), ept(EXT_WORDS * n), a(8 * B), c(8 * B), ws(WS_WORDS_PER_LANE + 4);
+    msig_params P{};
+    P.z = z; P.PK = PK; P.R = R; P.S = S; P.m = m; P.offsets = offsets; P.n_transcripts = (uint32_t)B; P.n_total = n;
+    P.share_status = status; P.agg_pk = agg_pk; P.sig_u = sig_u; P.sig_R = sig_R;
+    P.tr_of = tr.data(); P.d_words = d.data(); P.dpk = dpk.data(); P.e_pt = ept.data(); P.a_words = a.data(); P.c_words = c.data();
+    P.tags = &JJS_SPONGE_TAG_LONG[0][0]; P.comb_g = g_comb_g.data();
+    uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+    for (size_t t = 0; t < B; ++t) msig_map_item(P, (uint32_t)t);
+    for (size_t i = 0; i < n; ++i) msig_delin_item(P, i, w);
+    for (size_t t = 0; t < B; ++t) msig_agg_item(P, (uint32_t)t);
+    for (size_t i = 0; i < n; ++i) msig_commit_item(P, i, w);
+    for (size_t t = 0; t < B; ++t) msig_final_item(P, (uint32_t)t);
+    for (size_t i = 0; i < n; ++i) msig_share_item(P, i, w);
     return 0;
 }
 // comb table entry -> affine point bytes (u || v), recovered from the cached form

@@ -96,3 +96,12 @@ def half_size(c):
 def decompress(c):
     c = _c(c); out = np.empty((len(c), 64), np.uint8); ok = np.empty(len(c), np.uint8)
     load().jjs_host_decompress(_p(c), ctypes.c_size_t(len(c)), _p(out), _p(ok)); return out, ok
+
+
+def multisig(z, PK, R, S, m, offsets):
+    z, PK, R, S, m = _c(z), _c(PK), _c(R), _c(S), _c(m)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint32)
+    B, N = len(offs) - 1, len(z)
+    status = np.empty(N, np.uint8); agg = np.empty((B, 64), np.uint8); su = np.empty((B, 32), np.uint8); sr = np.empty((B, 64), np.uint8)
+    load().jjs_host_multisig(_p(z), _p(PK), _p(R), _p(S), _p(m), _p(offs), ctypes.c_size_t(B), _p(status), _p(agg), _p(su), _p(sr))
+    return status, agg, su, sr

@@ -289,3 +289,30 @@ def test_verify_wire_golden_serde_bytes(eng, reference_kat):
     st, _ = eng.verify_wire("single", A(bytes.fromhex(k["signature"]), 64), A(bytes.fromhex(k["aggregate_public_key"]), 32),
                             A(o.le32(k["message"]), 32))
     assert host(st).tolist() == [0]
+
+
+# ---- multisig batch -------------------------------------------------------------------
+def test_multisig_batch(eng, reference_kat):
+    from test_hostbuild import check_multisig
+
+    def run(z, PK, R, S, m, offs):
+        out = eng.multisig_combine(dev(z), dev(PK), dev(R), dev(S), dev(m), offs)
+        return tuple(host(t) for t in out)
+    check_multisig(run, reference_kat)
+
+
+def test_multisig_many_transcripts(eng):
+    """4096 copies of ragged oracle transcripts (different corruption pattern per copy is not needed:
+    the point is many transcripts in flight and the per-transcript outputs staying separate)."""
+    from helpers import make_multisig_batch
+    z, PK, R, S, m, offs, want, info = make_multisig_batch(8, seed=33, max_n=6)
+    reps = 512
+    n = len(z)
+    Z, P_, R_, S_, M = (np.tile(a, (reps, 1)) for a in (z, PK, R, S, m))
+    offs_all = np.concatenate([[0]] + [offs[1:].astype(np.int64) + r * n for r in range(reps)]).astype(np.uint32)
+    st, agg, su, sr = (host(t) for t in eng.multisig_combine(dev(Z), dev(P_), dev(R_), dev(S_), dev(M), offs_all))
+    assert (st.reshape(reps, n) == want[None, :]).all()
+    assert (agg.reshape(reps, len(info), 64) == agg[:len(info)][None]).all()
+    assert (sr.reshape(reps, len(info), 64) == sr[:len(info)][None]).all() and (su.reshape(reps, len(info), 32) == su[:len(info)][None]).all()
+    for t, (a_pk, u, rsa) in enumerate(info):
+        assert su[t].tobytes() == o.le32(u)

@@ -142,3 +142,31 @@ def test_decompress_matches_oracle():
         else:
             assert out[i].tobytes() == o.le32(want[0]) + o.le32(want[1]), i
     assert n_fail >= 10
+
+
+def check_multisig(run, reference_kat):
+    from helpers import make_multisig_batch, pt_bytes
+    # 1. the reference's KAT transcript (src/multisig.rs:544-672): shares valid, combined signature bytes
+    k = reference_kat["multisig_kat"]
+    pks = [o.decompress(bytes.fromhex(x)) for x in k["public_keys"]]
+    Rs = [o.decompress(bytes.fromhex(x)) for x in k["r_points"]]; Ss = [o.decompress(bytes.fromhex(x)) for x in k["s_points"]]
+    z = np.stack([np.frombuffer(bytes.fromhex(x), np.uint8) for x in k["individual_shares"]])
+    st, agg, su, sr = run(z, pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
+    assert st.tolist() == [0, 0, 0]
+    from helpers import to_pt
+    assert o.compress(to_pt(agg[0])).hex() == k["aggregate_public_key"]
+    assert (su[0].tobytes() + o.compress(to_pt(sr[0]))).hex() == k["signature"]
+    # swapped shares -> InvalidMultisigShare at those slots
+    st, *_ = run(z[[1, 0, 2]], pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
+    assert st.tolist() == [4, 4, 0]
+    # 2. random ragged transcripts
+    z, PK, R, S, m, offs, want, info = make_multisig_batch(7, seed=9)
+    st, agg, su, sr = run(z, PK, R, S, m, offs)
+    assert st.tolist() == want.tolist()
+    for t, (a_pk, u, rsa) in enumerate(info):
+        assert agg[t].tobytes() == pt_bytes(a_pk).tobytes() and sr[t].tobytes() == pt_bytes(rsa).tobytes()
+        assert su[t].tobytes() == o.le32(u)
+
+
+def test_multisig_batch(reference_kat):
+    check_multisig(hl.multisig, reference_kat)

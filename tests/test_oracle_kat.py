@@ -173,3 +173,18 @@ def test_legacy_double_attack_is_rejected(reference_kat):
     assert o._equation(o.G, u, pk, legacy_c, r) and o._equation(o.G_NUMS, u, pkp, legacy_c, rp)
     # ... the real verifier rejects (tests/schnorr_double.rs:72-82)
     assert o.verify_double(u, r, rp, pk, pkp, m) == reference_kat["legacy_double_attack"]["expected_status"]
+
+
+def test_multisig_shares_and_combine(reference_kat):
+    """verify_share / combine / sign_round_2 restatements against the multisig KAT."""
+    k = reference_kat["multisig_kat"]
+    sks, rs, ss, m = k["secret_keys"], k["r_scalars"], k["s_scalars"], k["message"]
+    pks = [o.mul(o.G, s) for s in sks]; Rs = [o.mul(o.G, s) for s in rs]; Ss = [o.mul(o.G, s) for s in ss]
+    zs = [o.multisig_sign_share(sks[i], rs[i], ss[i], pks, Rs, Ss, m) for i in range(3)]
+    assert [o.le32(z).hex() for z in zs] == k["individual_shares"]
+    assert all(o.multisig_verify_share(zs[i], i, pks, Rs, Ss, m) for i in range(3))
+    assert not o.multisig_verify_share(zs[0], 1, pks, Rs, Ss, m)
+    assert not o.multisig_verify_share((zs[2] + 1) % o.R_ORDER, 2, pks, Rs, Ss, m)
+    (u, rsa), bad = o.multisig_combine(zs, pks, Rs, Ss, m)
+    assert bad is None and (o.le32(u) + o.compress(rsa)).hex() == k["signature"]
+    assert o.multisig_combine([zs[0], zs[2], zs[1]], pks, Rs, Ss, m) == (None, 1)
