@@ -66,13 +66,18 @@ struct decode_params {
     uint8_t* bad;         // n bytes, set to 1 when any source of item i fails to decode (nullable)
     uint8_t* ok;          // n bytes, 1/0 per item for source 0 (nullable; debug entry point)
     uint64_t n;
+    dlog_tables dlog;
 };
+__global__ __launch_bounds__(BLOCK) void dlog_table_kernel(uint32_t* pow, uint8_t* hash) {
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < 7 * 256) dlog_table_entry(pow, hash, t / 256, t % 256);
+}
 __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total) {
         bool all_ok = true;
         for (uint32_t k = 0; k < P.n_src; ++k) {
-            decoded_point d = decompress_point(load_words(P.src[k], item));
+            decoded_point d = decompress_point(load_words(P.src[k], item), P.dlog);
             store_words(P.out[k], 2 * item, d.u);
             store_words(P.out[k], 2 * item + 1, d.v);
             all_ok = all_ok && d.ok;
@@ -155,6 +160,8 @@ struct engine {
     unsigned long long* tally = nullptr;
     int grid_verify = 0, grid_sign = 0;
     size_t ws_lanes = 0;
+    uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
+    uint8_t* dlog_hash = nullptr;
     uint32_t* tags_long = nullptr; // SAFE tags for long transcripts (multisig)
     uint8_t* msig = nullptr;       // multisig scratch
     size_t msig_items = 0, msig_transcripts = 0;
@@ -266,6 +273,10 @@ int jjs_init(int device_count) {
     HIP_TRY(hipMalloc(&g.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&g.tag, 32));
     HIP_TRY(hipMalloc(&g.tally, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&g.dlog_pow, DLOG_POW_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&g.dlog_hash, 65536));
+    HIP_TRY(hipMemsetAsync(g.dlog_hash, 0, 65536, g.stream));
+    hipLaunchKernelGGL(dlog_table_kernel, dim3(7), dim3(BLOCK), 0, g.stream, g.dlog_pow, g.dlog_hash);
     HIP_TRY(hipMalloc(&g.tags_long, sizeof(JJS_SPONGE_TAG_LONG)));
     HIP_TRY(hipMemcpyAsync(g.tags_long, JJS_SPONGE_TAG_LONG, sizeof(JJS_SPONGE_TAG_LONG), hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(g.tag, JJS_DOUBLE_TAG_WORDS, 32, hipMemcpyHostToDevice, g.stream));
@@ -288,6 +299,7 @@ void jjs_shutdown(void) {
     if (g.msig) (void)hipFree(g.msig);
     g.msig = nullptr; g.msig_items = g.msig_transcripts = 0;
     (void)hipFree(g.tags_long); g.tags_long = nullptr;
+    (void)hipFree(g.dlog_pow); (void)hipFree(g.dlog_hash); g.dlog_pow = nullptr; g.dlog_hash = nullptr;
     (void)hipStreamDestroy(g.stream);
     g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
     g.ready = false;
@@ -401,6 +413,7 @@ static uint8_t* wire_pts(int k) { return g.wire + (size_t)k * g.wire_items * 64;
 static uint8_t* wire_bad() { return g.wire + (size_t)4 * g.wire_items * 64; }
 
 static int launch_decode(decode_params D, hipStream_t s) {
+    D.dlog = dlog_tables{g.dlog_pow, g.dlog_hash};
     size_t blocks = (D.n + BLOCK - 1) / BLOCK;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, D);

@@ -332,6 +332,30 @@ def main():
         L.append("JJS_CONST uint32_t JJS_%s_SW[JJS_%s_SW_STEPS][2] = {" % (name, name) + ", ".join("{%d, %d}" % st for st in steps) + "};")
     zeta = pow(7, t_odd, Q)
     assert pow(zeta, 1 << 31, Q) == Q - 1, "7 must be a non-residue"
+    # 2-adic discrete logarithm by bytes (decode.h): bases of the seven 256-entry power tables, built on
+    # the device at init, and a perfect hash of the 256 elements of the order-256 subgroup
+    zi = inv(zeta)
+    bases = [zi, pow(zi, 1 << 8, Q), pow(zi, 1 << 16, Q),                  # B_i[j] = zeta^(-j * 2^(8i)), i = 0..2
+             zi, pow(zi, 1 << 7, Q), pow(zi, 1 << 15, Q), pow(zi, 1 << 23, Q)]  # A_0[j] = zeta^(-(j >> 1)), A_i[j] = zeta^(-j * 2^(8i-1))
+    L.append("JJS_CONST uint32_t JJS_DLOG_BASES[7][9] = {" + ", ".join(limbs29(mont(x)) for x in bases) + "};")
+    g8 = pow(zeta, 1 << 24, Q)
+    elems = [mont(pow(g8, j, Q)) for j in range(256)]
+    assert len(set(elems)) == 256
+    found = None
+    for mult in range(1, 1 << 12, 2):
+        for shift in range(0, 14):
+            keys = [(((e & 0x1FFFFFFF) * mult) >> shift) & 0xFFFF for e in elems]
+            if len(set(keys)) == 256:
+                found = (mult, shift)
+                break
+        if found:
+            break
+    assert found, "no collision-free hash found"
+    mult, shift = found
+    L.append("// dlog in the order-256 subgroup: index = ((limb0 * MULT) >> SHIFT) & 0xffff of the canonical Montgomery")
+    L.append("// limbs into a 64 KiB byte table that the engine fills on the device at init (collision-free: checked here)")
+    L.append("#define JJS_DLOG_HASH_MULT %du" % mult)
+    L.append("#define JJS_DLOG_HASH_SHIFT %d" % shift)
     L.append("JJS_CONST uint32_t JJS_ROOT_OF_UNITY[9] = %s;  // 7^((q-1)/2^32): generator of the 2^32-torsion of Fq*" % limbs29(mont(zeta)))
     L.append("JJS_CONST uint32_t JJS_ONE_PLUS_Q[9] = %s;  // the other representative of 1 below 2q" % limbs29(MONT + Q))
     L.append("JJS_CONST uint32_t JJS_RC[%d][9] = {" % len(rc))

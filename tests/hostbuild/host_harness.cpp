@@ -115,10 +115,17 @@ int jjs_host_half_size(const uint8_t* c, size_t n, uint8_t* out) {
 }
 // compressed (n x 32) -> affine (n x 64) + ok byte
 int jjs_host_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+    static std::vector<uint32_t> pw;
+    static std::vector<uint8_t> hs;
+    if (pw.empty()) {
+        pw.resize(DLOG_POW_WORDS); hs.assign(65536, 0);
+        for (int i = 0; i < 7; ++i) for (int j = 0; j < 256; ++j) dlog_table_entry(pw.data(), hs.data(), i, j);
+    }
+    const dlog_tables T{pw.data(), hs.data()};
     for (size_t i = 0; i < n; ++i) {
         words8 w;
         memcpy(w.w, in + 32 * i, 32);
-        decoded_point d = decompress_point(w);
+        decoded_point d = decompress_point(w, T);
         memcpy(out + 64 * i, d.u.w, 32); memcpy(out + 64 * i + 32, d.v.w, 32);
         ok[i] = d.ok ? 1 : 0;
     }
