@@ -150,6 +150,35 @@ int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, con
     for (size_t i = 0; i < n; ++i) msig_share_item(P, i, w);
     return 0;
 }
+// raw entry points on arbitrary (un-normalised) limb vectors, for the bound-edge tests: n x 9 uint32 each
+int jjs_host_raw_mul(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        raw9 r = mont_mul_body(a + 9 * i, b + 9 * i);
+        memcpy(out + 9 * i, r.l, 36);
+    }
+    return 0;
+}
+int jjs_host_raw_sqr(const uint32_t* a, size_t n, uint32_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        raw9 r = mont_sqr_body(a + 9 * i);
+        memcpy(out + 9 * i, r.l, 36);
+    }
+    return 0;
+}
+// five-term dot product with the MDS row `row` and small-integer combination with JJS_HS_MAT[row]
+int jjs_host_raw_dot5(const uint32_t* t, int row, size_t n, uint32_t* out_dot, uint32_t* out_small) {
+    for (size_t i = 0; i < n; ++i) {
+        fe<1, 3> v[5];
+        for (int j = 0; j < 5; ++j) memcpy(v[j].l, t + 45 * i + 9 * j, 36);
+        fe_n d = fq_dot_const<5, 3>(JJS_MDS[row], v);
+        memcpy(out_dot + 9 * i, d.l, 36);
+        fe<2, 3> w[5];
+        for (int j = 0; j < 5; ++j) memcpy(w[j].l, t + 45 * i + 9 * j, 36);
+        fe_n s = fq_lincomb_small<5>(JJS_HS_MAT[row], w);
+        memcpy(out_small + 9 * i, s.l, 36);
+    }
+    return 0;
+}
 // comb table entry -> affine point bytes (u || v), recovered from the cached form
 int jjs_host_comb_entry(int which, int i, int b, uint8_t* out_ypx_ymx_t2d) {
     ensure_tables();

@@ -105,3 +105,22 @@ def multisig(z, PK, R, S, m, offsets):
     status = np.empty(N, np.uint8); agg = np.empty((B, 64), np.uint8); su = np.empty((B, 32), np.uint8); sr = np.empty((B, 64), np.uint8)
     load().jjs_host_multisig(_p(z), _p(PK), _p(R), _p(S), _p(m), _p(offs), ctypes.c_size_t(B), _p(status), _p(agg), _p(su), _p(sr))
     return status, agg, su, sr
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def raw_mul(a, b):
+    a, b = _u32(a), _u32(b); out = np.empty_like(a)
+    load().jjs_host_raw_mul(_p(a), _p(b), ctypes.c_size_t(len(a)), _p(out)); return out
+
+
+def raw_sqr(a):
+    a = _u32(a); out = np.empty_like(a)
+    load().jjs_host_raw_sqr(_p(a), ctypes.c_size_t(len(a)), _p(out)); return out
+
+
+def raw_dot5(t, row):
+    t = _u32(t); n = len(t); d = np.empty((n, 9), np.uint32); s = np.empty((n, 9), np.uint32)
+    load().jjs_host_raw_dot5(_p(t), row, ctypes.c_size_t(n), _p(d), _p(s)); return d, s

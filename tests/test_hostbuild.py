@@ -170,3 +170,70 @@ def check_multisig(run, reference_kat):
 
 def test_multisig_batch(reference_kat):
     check_multisig(hl.multisig, reference_kat)
+
+
+# ---- the static bounds of fq29.h, exercised at their edges ------------------------------------------------
+RP = 1 << 261
+
+
+def limbs_val(row):
+    return sum(int(x) << (29 * i) for i, x in enumerate(row))
+
+
+def edge_limb_vectors(rng, n, limb_units, value_units):
+    """Limb vectors with every limb < limb_units * 2^29 and value < value_units * q: random, plus vectors
+    pushed against both bounds."""
+    out = []
+    while len(out) < n:
+        kind = len(out) % 4
+        cap = limb_units << 29
+        if kind == 0:
+            l = [int(rng.integers(0, cap)) for _ in range(9)]
+        elif kind == 1:
+            l = [cap - 1] * 9                       # every limb at its maximum
+        elif kind == 2:
+            l = [cap - 1 - int(rng.integers(0, 4)) for _ in range(9)]
+        else:
+            l = [int(rng.integers(0, cap)) for _ in range(8)] + [cap - 1]
+        # clamp the value below value_units * q by lowering the top limb
+        lim = value_units * o.Q - 1
+        low = sum(x << (29 * i) for i, x in enumerate(l[:8]))
+        l[8] = min(l[8], max(0, (lim - low) >> 232))
+        if limbs_val(l) <= lim:
+            out.append(l)
+    return np.array(out, np.uint64).astype(np.uint32)
+
+
+def check_product(res, want_mod):
+    for i in range(len(res)):
+        v = limbs_val(res[i])
+        assert all(int(x) < 1 << 29 for x in res[i][:8]), i
+        assert v < 2 * o.Q, i
+        assert v % o.Q == want_mod[i], i
+
+
+def test_montgomery_product_at_the_edges_of_its_static_bounds():
+    """fq_mul demands La*Lb <= 6 and Aa*Ab <= 70; the result must be exact, < 2q, with normalised limbs."""
+    rng = np.random.default_rng(77)
+    rinv = pow(RP, -1, o.Q)
+    for (la, aa), (lb, ab) in (((1, 2), (1, 2)), ((3, 5), (2, 4)), ((6, 7), (1, 10)), ((2, 35), (3, 2)), ((1, 70), (1, 1)), ((3, 8), (2, 8))):
+        assert la * lb <= 6 and aa * ab <= 70
+        a, b = edge_limb_vectors(rng, 200, la, aa), edge_limb_vectors(rng, 200, lb, ab)
+        res = hl.raw_mul(a, b)
+        check_product(res, [limbs_val(a[i]) * limbs_val(b[i]) * rinv % o.Q for i in range(len(a))])
+    for la, aa in ((1, 2), (2, 4), (2, 8), (1, 8)):
+        assert la * la <= 6 and aa * aa <= 70
+        a = edge_limb_vectors(rng, 200, la, aa)
+        check_product(hl.raw_sqr(a), [limbs_val(x) ** 2 * rinv % o.Q for x in a])
+
+
+def test_dot_products_at_the_edges_of_their_static_bounds():
+    rng = np.random.default_rng(78)
+    rinv, inv29 = pow(RP, -1, o.Q), pow(1 << 29, -1, o.Q)
+    for row in range(5):
+        t = np.stack([edge_limb_vectors(rng, 120, 1, 3) for _ in range(5)], axis=1)      # (n, 5, 9), fe<1,3>
+        d, s = hl.raw_dot5(t.reshape(len(t), 45), row)
+        mds = [o.MDS[row][j] * RP % o.Q for j in range(5)]                                  # Montgomery constants
+        check_product(d, [sum(mds[j] * limbs_val(t[i, j]) for j in range(5)) * rinv % o.Q for i in range(len(t))])
+        small = [360360 // (row + j + 5) for j in range(5)]
+        check_product(s, [sum(small[j] * limbs_val(t[i, j]) for j in range(5)) * inv29 % o.Q for i in range(len(t))])
