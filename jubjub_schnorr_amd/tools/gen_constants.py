@@ -365,25 +365,6 @@ def main():
     for trial in range(3):
         st = [int.from_bytes(hashlib.sha256(b"hades-selfcheck-%d-%d" % (trial, i)).digest(), "little") % Q for i in range(WIDTH)]
         assert hades_reference(st) == hades_optimised(st, kappa, full, row_z3, row_y, m_pre, m_last), "optimised Hades differs"
-    L.append("// optimised Hades (see optimised_hades() in the generator)")
-    L.append("JJS_CONST uint32_t JJS_HF_RC[%d][5][9] = {" % N_FULL)
-    L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in full]
-    L.append("};")
-    L.append("JJS_CONST uint32_t JJS_HP_KAPPA[%d][9] = {" % N_PARTIAL)
-    L += ["  %s," % limbs29(mont(x)) for x in kappa]
-    L.append("};")
-    L.append("// partial rounds in controller canonical form: rows for z3' and y' over (z0, z1, z2, z3, x)")
-    L.append("JJS_CONST uint32_t JJS_HP_ROWS[2][5][9] = {")
-    for row in (row_z3, row_y):
-        L.append("  {" + ", ".join(limbs29(mont(x)) for x in row) + "},")
-    L.append("};")
-    L.append("// dense matrices: [0] = MDS, [1] = diag(T^-1,1) MDS (enters the canonical basis), [2] = MDS diag(T,1) (leaves it)")
-    L.append("JJS_CONST uint32_t JJS_HD_MAT[3][5][5][9] = {")
-    for mat in (m, m_pre, m_last):
-        L.append(" {")
-        L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in mat]
-        L.append(" },")
-    L.append("};")
     rc_full, kap, mu, lam_end = scaled_hades_constants()
     assert all(SMALL_S[i][j] * (i + j + 5) == SMALL_L and SMALL_S[i][j] < 1 << 17 for i in range(5) for j in range(5))
     for trial in range(3):

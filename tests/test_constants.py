@@ -62,13 +62,20 @@ def test_poseidon_constants():
     assert [limbs(r) for r in mds] == [mont(o.MDS[i][j]) for i in range(5) for j in range(5)]
 
 
-def test_optimised_hades_tables_are_consistent():
-    """The optimised permutation is checked end to end by the Poseidon parity tests; here: shapes, the
-    plain MDS copy, and that the canonical-form rows are what the generator's own model uses."""
-    mats = arrays("JJS_HD_MAT")
-    assert len(mats) == 75
-    assert [limbs(r) for r in mats[:25]] == [mont(o.MDS[i][j]) for i in range(5) for j in range(5)]
-    assert len(arrays("JJS_HP_KAPPA")) == 60 and len(arrays("JJS_HP_ROWS")) == 10 and len(arrays("JJS_HF_RC")) == 40
-    rows = arrays("JJS_HP_ROWS")
-    assert limbs(rows[4]) == mont(1)                      # z3' = -alpha.z + 1*x
-    assert limbs(rows[9]) == mont(o.MDS[4][4])            # y'  = (T^T w).z + m44*x
+def test_scaled_hades_tables_are_consistent():
+    """The scaled small-matrix permutation is checked end to end by the Poseidon parity tests (and by the
+    generator's own model against the textbook rounds); here: the matrix really is L / (i + j + 5) and the
+    table shapes are what hades29.h indexes."""
+    m = re.search(r"JJS_CONST uint32_t JJS_HS_MAT\[5\]\[5\] = (.*?);", INC, re.S).group(1)
+    rows = [[int(x) for x in re.findall(r"\d+", grp)] for grp in re.findall(r"\{([^{}]*)\}", m)]
+    assert rows == [[360360 // (i + j + 5) for j in range(5)] for i in range(5)]
+    assert all(360360 % (i + j + 5) == 0 for i in range(5) for j in range(5))
+    assert len(arrays("JJS_HS_RC_FULL")) == 40 and len(arrays("JJS_HS_KAPPA")) == 60 and len(arrays("JJS_HS_MU")) == 60
+    # round 0 runs at scale 1: its constants are the textbook ones
+    assert [limbs(r) for r in arrays("JJS_HS_RC_FULL")[:5]] == [mont(c) for c in o.RC[:5]]
+    # scale recurrence: full rounds lambda' = lambda^5 * step, so after round 0 lambda_1 = step = F/L * 2^29
+    step = pow(2, 256, o.Q) * pow(360360, -1, o.Q) * (1 << 29) % o.Q
+    lam = 1
+    for _ in range(4):
+        lam = pow(lam, 5, o.Q) * step % o.Q
+    assert limbs(arrays("JJS_HS_MU")[0]) == mont(pow(lam, 4, o.Q))

@@ -170,7 +170,7 @@ def test_gpu_signer_matches_oracle(eng, scheme):
         assert (host(a) == b).all()
 
 
-@pytest.mark.parametrize("scheme,log2n", [("single", 20), ("double", 18), ("vargen", 18)])
+@pytest.mark.parametrize("scheme,log2n", [("single", 20), ("double", 20), ("vargen", 20)])
 def test_full_size_properties(eng, scheme, log2n):
     """BASELINE-size batch: inputs from the GPU signer, known corruption pattern, so the expected
     status of every item is known by construction; plus an oracle check of a random sample."""
