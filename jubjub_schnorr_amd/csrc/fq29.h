@@ -41,6 +41,7 @@
 namespace jjs {
 
 #include "jjs_constants.inc"
+#include "mont_asm.inc"
 
 constexpr uint32_t MASK29 = 0x1fffffffu;
 
@@ -178,6 +179,14 @@ JJS_HD fe<L, A> fq_select(bool c, const fe<L, A>& a, const fe<L, A>& b) {  // c 
 // Montgomery product (a*b + M*q) / 2^261, column by column.  -q^-1 = -1 mod 2^29 and q0 = 1, so the
 // quotient digit is m_k = -acc mod 2^29 and adding m_k*q0 just rounds the column up.
 // ---------------------------------------------------------------------------------------------
+// low column epilogue: m = -acc mod 2^29 makes acc + m*q0 (q0 = 1) divisible by 2^29; the carry into the
+// next column is (acc + m) >> 29 = (acc + (2^29 - 1)) >> 29
+JJS_HD uint32_t mont_digit(uint64_t& acc) {
+    const uint32_t m = (0u - (uint32_t)acc) & MASK29;
+    acc = (acc + MASK29) >> 29;
+    return m;
+}
+
 JJS_HD raw9 mont_mul_body(const uint32_t* a, const uint32_t* b) {
     uint32_t m[9];
     raw9 r;
@@ -188,9 +197,7 @@ JJS_HD raw9 mont_mul_body(const uint32_t* a, const uint32_t* b) {
         for (int i = 0; i <= k; ++i) acc += (uint64_t)a[i] * b[k - i];
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * q29(k - i);
-        m[k] = (0u - (uint32_t)acc) & MASK29;
-        acc += m[k];
-        acc >>= 29;
+        m[k] = mont_digit(acc);
     }
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
@@ -219,14 +226,13 @@ JJS_HD raw9 mont_sqr_body(const uint32_t* a) {
         if (k < 9) {
 #pragma unroll
             for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * q29(k - i);
-            m[k] = (0u - (uint32_t)acc) & MASK29;
-            acc += m[k];
+            m[k] = mont_digit(acc);
         } else {
 #pragma unroll
             for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * q29(k - i);
             r.l[k - 9] = (uint32_t)acc & MASK29;
+            acc >>= 29;
         }
-        acc >>= 29;
     }
     r.l[8] = (uint32_t)acc;
     return r;
@@ -238,14 +244,35 @@ JJS_HD raw9 mont_sqr_body(const uint32_t* a) {
 JJS_CALL raw9 mont_mul_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
                             uint32_t a6, uint32_t a7, uint32_t a8, uint32_t b0, uint32_t b1, uint32_t b2,
                             uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
+    // one hand-scheduled block (tools/gen_mont_asm.py): 153 v_mad_u64_u32 in a single accumulator chain +
+    // 52 shifts/masks; the result limb j overwrites a_j
+    asm(JJS_MONT_MUL_ASM
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
+          [a7] "+v"(a7), [a8] "+v"(a8)
+        : [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [b4] "v"(b4), [b5] "v"(b5), [b6] "v"(b6), [b7] "v"(b7),
+          [b8] "v"(b8)
+        : JJS_MONT_ASM_CLOBBERS);
+    return raw9{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+#else
     const uint32_t a[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
     const uint32_t b[9] = {b0, b1, b2, b3, b4, b5, b6, b7, b8};
     return mont_mul_body(a, b);
+#endif
 }
 JJS_CALL raw9 mont_sqr_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
                             uint32_t a6, uint32_t a7, uint32_t a8) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
+    asm(JJS_MONT_SQR_ASM
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
+          [a7] "+v"(a7), [a8] "+v"(a8)
+        :
+        : JJS_MONT_ASM_CLOBBERS);
+    return raw9{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+#else
     const uint32_t a[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
     return mont_sqr_body(a);
+#endif
 }
 
 template <int La, int Aa, int Lb, int Ab>
