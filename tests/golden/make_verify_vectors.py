@@ -78,6 +78,47 @@ def main():
     add_double("legacy_double_attack", u, r, rp, pk, pkp, m)
     assert out["double"][-1]["status"] == a["expected_status"]
 
+    # cross-generator forgery (reference tests/schnorr_var_generator.rs:61-113, seed 0xdead): expected
+    # InvalidSignature; under the generator-free legacy challenge the forged pair would verify
+    rng = o.StdRng(0xDEAD)
+    sk = rng.random_fr(); g = rng.random_fr(); gen = o.mul(o.G, g); pkv = o.mul(gen, sk)
+    m = rng.random_fq()
+    u, R = o.sign_vargen(rng, sk, gen, m)
+    add_vargen("cross_generator_original", u, R, pkv, gen, m)
+    assert out["vargen"][-1]["status"] == 0
+    p_pt = o.mul(o.G, rng.random_fr())
+    c_prime = o.digest_truncated([R[0], R[1], p_pt[0], p_pt[1], m])
+    g2 = o.mul(o.add(R, o.neg(o.mul(p_pt, c_prime))), pow(u, -1, o.R_ORDER))
+    assert o._equation(g2, u, p_pt, c_prime, R)          # the attack works against the legacy transcript
+    add_vargen("cross_generator_forgery", u, R, p_pt, g2, m)
+    assert out["vargen"][-1]["status"] == 2
+    # sk = 0 with seeded messages (tests/schnorr.rs:58-66 seed 0xbeef-style cases): identity keys
+    for scheme, seed in (("single", 0xBEEF), ("double", 0xBEEF), ("vargen", 0xBEEF)):
+        rng = o.StdRng(seed)
+        m = rng.random_fq()
+        if scheme == "single":
+            u, R = o.sign_single(rng, 0, m)
+            add_single("sk_zero_identity_pk", u, R, o.IDENTITY, m)
+            assert out["single"][-1]["status"] == 1
+        elif scheme == "double":
+            u, R, Rp = o.sign_double(rng, 0, m)
+            add_double("sk_zero_identity_pk", u, R, Rp, o.IDENTITY, o.IDENTITY, m)
+            assert out["double"][-1]["status"] == 1
+        else:
+            u, R = o.sign_vargen(rng, 0, o.G, m)
+            add_vargen("sk_zero_identity_pk", u, R, o.IDENTITY, o.G, m)
+            assert out["vargen"][-1]["status"] == 1
+    # challenge binds both public keys (reference src/signatures/double.rs:190-217)
+    r, rp, m13 = o.mul(o.G, 11), o.mul(o.G_NUMS, 11), 13
+    pk17, pkp17 = o.mul(o.G, 17), o.mul(o.G_NUMS, 17)
+    base_c = o.challenge_double(r, rp, pk17, pkp17, m13)
+    assert base_c != o.challenge_double(r, rp, o.add(pk17, o.G), pkp17, m13)
+    assert base_c != o.challenge_double(r, rp, pk17, o.add(pkp17, o.G_NUMS), m13)
+    add_double("challenge_binds_pk_base", 1, r, rp, pk17, pkp17, m13)
+    add_double("challenge_binds_pk_changed_pk", 1, r, rp, o.add(pk17, o.G), pkp17, m13)
+    add_double("challenge_binds_pk_changed_pk_prime", 1, r, rp, pk17, o.add(pkp17, o.G_NUMS), m13)
+    assert len({v["c"] for v in out["double"][-3:]}) == 3
+
     with open(os.path.join(HERE, "verify_vectors.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")

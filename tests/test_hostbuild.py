@@ -237,3 +237,16 @@ def test_dot_products_at_the_edges_of_their_static_bounds():
         check_product(d, [sum(mds[j] * limbs_val(t[i, j]) for j in range(5)) * rinv % o.Q for i in range(len(t))])
         small = [360360 // (row + j + 5) for j in range(5)]
         check_product(s, [sum(small[j] * limbs_val(t[i, j]) for j in range(5)) * inv29 % o.Q for i in range(len(t))])
+
+
+def test_golden_vectors_on_the_host_build():
+    """tests/golden/verify_vectors.json (the reference's own scenarios) through the CPU build."""
+    import json, os
+    from helpers import ARG_ORDER
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "verify_vectors.json")))
+    H = lambda x: np.frombuffer(bytes.fromhex(x), np.uint8)  # noqa: E731
+    for scheme, items in vec.items():
+        b = {k: np.stack([H(v[k]) for v in items]) for k in ARG_ORDER[scheme]}
+        st, _, c = hl.verify(scheme, b, want_c=True)
+        assert st.tolist() == [v["status"] for v in items], scheme
+        assert [r.tobytes().hex() for r in c] == [v["c"] for v in items], scheme
