@@ -62,6 +62,14 @@ def lib():
             raise JjsError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # If PyTorch is going to share the process it must be loaded first: it ships its own libamdhip64
+        # (same SONAME), and the dynamic loader then binds this library to that copy, so that both see
+        # one HIP runtime (one current device, shared device pointers and streams).  Loaded the other
+        # way round torch finds no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = ctypes.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI and the header diverge
