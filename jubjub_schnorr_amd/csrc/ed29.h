@@ -56,18 +56,18 @@ JJS_HD niels_pt niels_select(bool c, const niels_pt& a, const niels_pt& b) {
 // E = 2XY is a product, not (X+Y)^2 - X^2 - Y^2: one multiply costs about what the two extra
 // subtractions and their carry propagation would, and keeps E below 4q.
 JJS_HD ext_pt ext_double(const ext_pt& p, bool need_t) {
-    fe_n xx = fq_sqr(p.x);
-    fe_n yy = fq_sqr(p.y);
-    auto c2 = fq_dbl(fq_sqr(p.z));             // 2Z^2            <2,4>
-    auto e = fq_dbl(fq_mul(p.x, p.y));         // 2XY             <2,4>
+    fe_n xx = fq_sqr_hot(p.x);
+    fe_n yy = fq_sqr_hot(p.y);
+    auto c2 = fq_dbl(fq_sqr_hot(p.z));             // 2Z^2            <2,4>
+    auto e = fq_dbl(fq_mul_hot(p.x, p.y));         // 2XY             <2,4>
     auto g = fq_add(yy, xx);                   // Y^2 + X^2       <2,4>
     auto h = fq_norm(fq_sub(yy, xx));          // Y^2 - X^2       <1,5>
     auto f = fq_norm(fq_sub(c2, h));           // 2Z^2 - (Y^2 - X^2)  <1,10>
     ext_pt r;
-    r.x = fq_mul(e, f);
-    r.y = fq_mul(g, h);
-    r.z = fq_mul(f, h);
-    if (need_t) r.t = fq_mul(e, g); else r.t = fe_n_zero();
+    r.x = fq_mul_hot(e, f);
+    r.y = fq_mul_hot(g, h);
+    r.z = fq_mul_hot(f, h);
+    if (need_t) r.t = fq_mul_hot(e, g); else r.t = fe_n_zero();
     return r;
 }
 
@@ -76,19 +76,19 @@ JJS_HD ext_pt ext_add_niels(const ext_pt& p, const niels_pt& n, bool neg, bool n
     fe_t n_ymx = fq_select(neg, n.ypx, n.ymx);
     fe_t n_ypx = fq_select(neg, n.ymx, n.ypx);
     auto n_t2d = fq_select(neg, fq_neg(n.t2d), fq_as<2, 6>(n.t2d));   // <2,6>
-    fe_n a = fq_mul(fq_sub(p.y, p.x), n_ymx);      // <3,5> x <1,5>
-    fe_n b = fq_mul(fq_add(p.y, p.x), n_ypx);      // <2,4> x <1,5>
-    fe_n c = fq_mul(p.t, n_t2d);                   // <1,2> x <2,6>
-    auto d = fq_dbl(fq_mul(p.z, n.z));             // <2,4>
+    fe_n a = fq_mul_hot(fq_sub(p.y, p.x), n_ymx);      // <3,5> x <1,5>
+    fe_n b = fq_mul_hot(fq_add(p.y, p.x), n_ypx);      // <2,4> x <1,5>
+    fe_n c = fq_mul_hot(p.t, n_t2d);                   // <1,2> x <2,6>
+    auto d = fq_dbl(fq_mul_hot(p.z, n.z));             // <2,4>
     auto e = fq_sub(b, a);                         // <3,5>
     auto f = fq_norm(fq_sub(d, c));                // <1,7>
     auto g = fq_add(d, c);                         // <3,6>
     auto h = fq_add(b, a);                         // <2,4>
     ext_pt r;
-    r.x = fq_mul(e, f);
-    r.y = fq_mul(g, h);
-    r.z = fq_mul(f, g);
-    if (need_t) r.t = fq_mul(e, h); else r.t = fe_n_zero();
+    r.x = fq_mul_hot(e, f);
+    r.y = fq_mul_hot(g, h);
+    r.z = fq_mul_hot(f, g);
+    if (need_t) r.t = fq_mul_hot(e, h); else r.t = fe_n_zero();
     return r;
 }
 // P + N where N is affine (Z2 = 1): 7M (6M without T)

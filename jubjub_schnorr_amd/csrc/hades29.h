@@ -16,9 +16,15 @@ struct hades_state {
 
 template <int L, int A>
 JJS_HD fe_n sbox5(const fe<L, A>& x) {
+#if defined(JJS_HOT_SBOX)
+    fe_n x2 = fq_sqr_hot(x);
+    fe_n x4 = fq_sqr_hot(x2);
+    return fq_mul_hot(x4, x);
+#else
     fe_n x2 = fq_sqr(x);
     fe_n x4 = fq_sqr(x2);
     return fq_mul(x4, x);
+#endif
 }
 
 // The permutation (constants and derivation: scaled_hades_constants() in tools/gen_constants.py).

@@ -316,3 +316,33 @@ def test_multisig_many_transcripts(eng):
     assert (sr.reshape(reps, len(info), 64) == sr[:len(info)][None]).all() and (su.reshape(reps, len(info), 32) == su[:len(info)][None]).all()
     for t, (a_pk, u, rsa) in enumerate(info):
         assert su[t].tobytes() == o.le32(u)
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_differential_32k_against_c_oracle(eng, scheme):
+    """Every status byte and every challenge of a 2^15-item mixed batch (oracle-signed, oracle-corrupted:
+    wrong keys, tampered messages, identity / order-2 / mixed-order points) against the C oracle."""
+    n = 1 << 15
+    b = make_batch(scheme, n, seed=4242, n_keys=512)
+    # extra adversarial rows: R or PK moved into every torsion coset, off-curve points, non-canonical scalars
+    t8 = torsion_generator()
+    rng = np.random.default_rng(6)
+    from helpers import pt_bytes, to_pt
+    for k in range(1, 8):
+        for name in ("R", "PK"):
+            i = int(rng.integers(0, n))
+            b[name][i] = pt_bytes(o.add(to_pt(b[name][i]), o.mul(t8, k)))
+    for i in rng.integers(0, n, 8):
+        b["R"][i, 32] ^= 1
+    for i in rng.integers(0, n, 4):
+        b["u"][i] = 0xFF
+    want, want_c = oracle_verify(scheme, b, want_c=True)
+    args = [dev(b[k]) for k in ARG_ORDER[scheme]]
+    st, tally = eng.verify(scheme, *args)
+    c = eng.challenge(scheme, *args[1:])
+    got = host(st)
+    assert (got == want).all(), np.where(got != want)[0][:10]
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    canonical = want != 3          # the oracle exports a challenge only for canonical inputs
+    assert (host(c)[canonical] == want_c[canonical]).all()
+    assert set(want.tolist()) == {0, 1, 2, 3}
