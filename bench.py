@@ -102,7 +102,7 @@ def make_inputs(eng, scheme: str, n: int, rank: int):
     return {k: v.contiguous() for k, v in a.items()}, expect
 
 
-def cpu_baseline(scheme: str, arrays: dict, gpu_status, budget_s: float = 12.0):
+def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budget_s: float = 12.0):
     """Oracle (C restatement of the reference's algorithm) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
@@ -125,10 +125,16 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, budget_s: float = 12.0):
     st = fn(*[host[k] for k in ARG_ORDER[scheme]], threads=threads, native=native)
     dt = time.perf_counter() - t0
     agree = bool((st == gpu_status[:n].cpu().numpy()).all())
+    c_agree = None
+    if gpu_challenge is not None:      # every debug challenge equal on a 2^16 sample
+        k = min(n, 1 << 16)
+        _, c = fn(*[host[x][:k] for x in ARG_ORDER[scheme]], threads=threads, native=native, want_c=True)
+        canonical = st[:k] != 3
+        c_agree = bool((c[canonical] == gpu_challenge[:k].cpu().numpy()[canonical]).all())
     return {"value": n / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
             "sample": f"first {n} items of the same {scheme} batch, oracle/jjs_oracle.c "
                       f"({'-march=native' if native else 'generic x86-64'}), {dt:.1f} s",
-            "statuses_equal_gpu": agree}
+            "statuses_equal_gpu": agree, "challenges_equal_gpu_on_2^16_sample": c_agree}
 
 
 def main():
@@ -267,7 +273,8 @@ def main():
             "alu_roofline": alu,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scheme, arrays, st)
+            gpu_c = eng.challenge(scheme, *[arrays[k][: 1 << 16] for k in ARG_ORDER[scheme][1:]])
+            out["cpu_baseline"] = cpu_baseline(scheme, arrays, st, gpu_c)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
