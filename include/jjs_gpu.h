@@ -105,6 +105,10 @@ int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, s
                                void* stream);
 int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                                void* stream);
+/* the same from host buffers, blocking (copy in, decode, verify, copy out) */
+int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]);
+int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]);
+int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]);
 /* JubJubAffine::from_bytes / to_bytes in bulk: in n x 32 -> affine n x 64 + ok n bytes; affine n x 64 -> n x 32 */
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream);
 int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream);

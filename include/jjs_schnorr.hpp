@@ -128,6 +128,19 @@ class PublicKey {
         if (tally) std::memcpy(tally, t, sizeof(t));
         return detail::results(status);
     }
+    // Batch verify straight from the reference's wire formats (`Signature::to_bytes` 64 B = u || R,
+    // `PublicKey::to_bytes` 32 B; reference src/signatures.rs:101-119, src/keys/public.rs:80-94): points are
+    // decompressed on the device; an undecodable item yields Error::BytesError, as `from_bytes` would.
+    struct ItemBytes { std::array<uint8_t, 32> pk; std::array<uint8_t, 64> sig; BlsScalar message; };
+    static std::vector<VerifyResult> verify_batch_bytes(const std::vector<ItemBytes>& items) {
+        const size_t n = items.size();
+        detail::Soa sig(n, 64), pk(n, 32), m(n, 32);
+        for (size_t i = 0; i < n; ++i) { sig.put(i, 0, items[i].sig); pk.put(i, 0, items[i].pk); m.put(i, 0, items[i].message); }
+        std::vector<uint8_t> status(n);
+        int rc = jjs_verify_single_wire(sig.data(), pk.data(), m.data(), n, status.data(), nullptr);
+        if (rc != JJS_OK) throw EngineError(rc, "jjs_verify_single_wire");
+        return detail::results(status);
+    }
   private:
     AffinePoint point_;
 };

@@ -28,6 +28,9 @@ SIGNATURES = {
     "jjs_verify_single_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_double_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_vargen_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
+    "jjs_verify_single_wire": [_P, _P, _P, _Z, _P, _P],
+    "jjs_verify_double_wire": [_P, _P, _P, _Z, _P, _P],
+    "jjs_verify_vargen_wire": [_P, _P, _P, _Z, _P, _P],
     "jjs_multisig_combine_dev": [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P],
     "jjs_decompress_dev": [_P, _Z, _P, _P, _P],
     "jjs_compress_dev": [_P, _Z, _P, _P],

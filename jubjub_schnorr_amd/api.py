@@ -127,8 +127,16 @@ class Engine:
         """Batch verify from the reference's wire formats (torch CUDA uint8 tensors): sig (n, 64|96|64) =
         u || R [|| R'], pk (n, 32|64|64) compressed, m (n, 32).  Points are decoded on the device; an
         undecodable item gets status 3.  Returns (status, tally), asynchronous on the current stream."""
-        import torch
         ws, wp, wm = self._WIRE_WIDTHS[scheme]
+        if not _is_torch(sig):       # numpy: blocking host-buffer call
+            hs, hp, hm = self._host(sig, ws), self._host(pk, wp), self._host(m, wm)
+            n = hs.shape[0]
+            status, tally = np.empty(n, np.uint8), np.zeros(4, np.uint64)
+            fn = getattr(self._lib, f"jjs_verify_{scheme}_wire")
+            _ffi.check(fn(*[h.ctypes.data_as(ctypes.c_void_p) for h in (hs, hp, hm)], n, status.ctypes.data_as(ctypes.c_void_p),
+                          tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}_wire")
+            return status, tally
+        import torch
         n = sig.shape[0]
         ptrs = [self._dev_ptr(sig, ws, n), self._dev_ptr(pk, wp, n), self._dev_ptr(m, wm, n)]
         status = torch.empty(max(n, 1), dtype=torch.uint8, device=sig.device)[:n] if want_status else None

@@ -421,9 +421,8 @@ static int launch_decode(decode_params D, hipStream_t s) {
     return JJS_OK;
 }
 
-int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                               void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+static int wire_single_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                              void* stream) {
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -441,9 +440,8 @@ int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, s
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
 }
-int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                               void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+static int wire_double_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                              void* stream) {
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -464,9 +462,8 @@ int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, s
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
 }
-int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                               void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+static int wire_vargen_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
+                              void* stream) {
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -484,6 +481,41 @@ int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, s
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
+}
+typedef int (*wire_fn)(const void*, const void*, const void*, size_t, void*, void*, void*);
+static int wire_host(wire_fn fn, const uint8_t* sig, size_t sig_w, const uint8_t* pk, size_t pk_w, const uint8_t* m, size_t n,
+                     uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (int rc = check_ready()) return rc;
+    if (n && (!sig || !pk || !m)) return fail(JJS_ERR_ARG, "null input pointer");
+    staged ds, dp, dm, dst;
+    int rc;
+    if ((rc = ds.up(sig, sig_w * n, g.stream)) || (rc = dp.up(pk, pk_w * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) ||
+        (rc = dst.alloc(n)))
+        return rc;
+    if ((rc = fn(ds.d, dp.d, dm.d, n, dst.d, g.tally, g.stream))) return rc;
+    return finish_host(dst, status, tally, n);
+}
+int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    return wire_single_locked(sig, pk, m, n, status, tally, stream);
+}
+int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    return wire_double_locked(sig, pk, m, n, status, tally, stream);
+}
+int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(g.mu);
+    return wire_vargen_locked(sig, pk, m, n, status, tally, stream);
+}
+int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    return wire_host(wire_single_locked, sig, 64, pk, 32, m, n, status, tally);
+}
+int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    return wire_host(wire_double_locked, sig, 96, pk, 64, m, n, status, tally);
+}
+int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    return wire_host(wire_vargen_locked, sig, 64, pk, 64, m, n, status, tally);
 }
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream) {
     std::lock_guard<std::mutex> lock(g.mu);

@@ -35,7 +35,9 @@ int main(int argc, char** argv) {
     while (std::getline(in, line)) {
         std::istringstream ss(line);
         std::string scheme, name; int want;
-        ss >> scheme >> name >> want;
+        ss >> scheme;
+        if (scheme == "wire") continue;
+        ss >> name >> want;
         std::vector<std::string> f; std::string tok;
         while (ss >> tok) f.push_back(tok);
         ++n;
@@ -60,6 +62,23 @@ int main(int argc, char** argv) {
     uint64_t want_tally[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < res.size(); ++i) { failures += expect(res[i], singles_want[i], "batch[" + std::to_string(i) + "]"); ++want_tally[singles_want[i]]; }
     for (int k = 0; k < 4; ++k) if (tally[k] != want_tally[k]) { std::printf("FAIL tally[%d]\n", k); ++failures; }
+    // wire entry point: the reference's own serialised bytes (line "wire single <name> <status> sig pk m")
+    {
+        std::ifstream in2(argv[1]);
+        std::vector<jjs::PublicKey::ItemBytes> wire; std::vector<int> wire_want;
+        while (std::getline(in2, line)) {
+            std::istringstream ss(line);
+            std::string tag, scheme, name; int want;
+            ss >> tag;
+            if (tag != "wire") continue;
+            ss >> scheme >> name >> want;
+            std::string a, b, c; ss >> a >> b >> c;
+            wire.push_back({unhex<32>(b), unhex<64>(a), unhex<32>(c)}); wire_want.push_back(want);
+        }
+        auto wres = jjs::PublicKey::verify_batch_bytes(wire);
+        for (size_t i = 0; i < wres.size(); ++i) failures += expect(wres[i], wire_want[i], "wire[" + std::to_string(i) + "]");
+        n += (int)wire.size();
+    }
     if (jjs::PublicKey::verify_batch({}).size() != 0) { std::puts("FAIL empty batch"); ++failures; }
     std::printf("%d vectors, %d failures\n", n, failures);
     return failures ? 1 : 0;

@@ -31,6 +31,20 @@ def test_cpp_mirror_reference_scenarios(tmp_path):
     for scheme, items in vec.items():
         for v in items:
             lines.append(" ".join([scheme, v["name"], str(v["status"])] + [v[k] for k in ORDER[scheme]]))
+    # wire lines: the reference's serialised signature / key bytes (tests/serde.rs seed 2321, multisig KAT),
+    # plus a corrupted encoding that from_bytes would reject
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jjs_oracle as o
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))
+    v = kat["serde_base58"]
+    rng = o.StdRng(v["seed"]); rng.random_fr(); m = o.le32(rng.random_fq()).hex()
+    sig, pk = o.b58decode(v["serde_signature"]).hex(), o.b58decode(v["serde_public_key"]).hex()
+    lines.append(f"wire single serde 0 {sig} {pk} {m}")
+    k = kat["multisig_kat"]
+    lines.append(f"wire single multisig_kat 0 {k['signature']} {k['aggregate_public_key']} {o.le32(k['message']).hex()}")
+    lines.append(f"wire single bad_pk_encoding 3 {sig} {o.le32(o.Q).hex()} {m}")
+    lines.append(f"wire single wrong_message 2 {sig} {pk} {o.le32(5).hex()}")
     path = tmp_path / "vectors.txt"
     path.write_text("\n".join(lines) + "\n")
     exe = build(tmp_path)

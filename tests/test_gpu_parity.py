@@ -268,6 +268,8 @@ def test_verify_wire(eng, scheme, n):
     st, tally = eng.verify_wire(scheme, dev(sig), dev(pk), dev(m))
     assert host(st).tolist() == want.tolist()
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    st_h, tally_h = eng.verify_wire(scheme, sig, pk, m)       # blocking host-buffer entry point
+    assert st_h.tolist() == want.tolist() and tally_h.tolist() == host(tally).tolist()
 
 
 def test_verify_wire_golden_serde_bytes(eng, reference_kat):
