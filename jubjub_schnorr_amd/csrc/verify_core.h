@@ -288,63 +288,101 @@ JJS_HD bool lt_words(const uint32_t (&a)[N], const uint32_t (&b)[N]) {  // a < b
     return borrow != 0;
 }
 
+// the 64 bits of x that start at bit position `pos` (pos may be negative: zero filled)
+JJS_HD uint64_t bits64_at(const uint32_t (&x)[8], int pos) {
+    // assemble from three words around pos
+    const int p = pos < 0 ? 0 : pos;
+    const int wi = p >> 5, sh = p & 31;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w0 = (i == wi) ? x[i] : w0;
+        w1 = (i == wi + 1) ? x[i] : w1;
+        w2 = (i == wi + 2) ? x[i] : w2;
+    }
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    uint64_t v = lo >> sh;
+    if (sh) v |= (uint64_t)w2 << (64 - sh);
+    return pos < 0 ? (v << (-pos)) : v;
+}
+
+// Euclid on (r, c), truncated at the first remainder below 2^126.  Each pass removes q' * r1 from r0 for a
+// partial quotient q' <= floor(r0 / r1) estimated from the leading 63 bits in double precision (clamped
+// to 31 significant bits, at least 1), so any pass is a valid step of the extended Euclidean algorithm and the
+// invariant r0*|t1| + r1*|t0| = r holds throughout; a swap happens only when the remainder has dropped
+// below r1.  ~75 passes instead of ~190 single-bit steps; the loop runs until the slowest lane of the
+// wave is done.
 JJS_HD half_scalars half_size_scalars(const words8& c) {
     uint32_t r0[8], r1[8], t0[4] = {0, 0, 0, 0}, t1[4] = {1, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 8; ++i) { r0[i] = JJS_FR_WORDS[i]; r1[i] = c.w[i]; }
     bool neg = false;   // sign of t1; t0 always has the opposite sign (or is zero)
-    for (;;) {
+    // Worst case (all quotients 1, Fibonacci-like) is ~185 passes; the bound only guarantees that every wave
+    // leaves the loop whatever happens.
+    for (int pass = 0; pass < 512; ++pass) {
         words8 w1;
 #pragma unroll
         for (int i = 0; i < 8; ++i) w1.w[i] = r1[i];
-        const int bl1 = bitlen256(w1);
-        const bool active = bl1 > 126;
+        const bool active = bitlen256(w1) > 126;
         if (!wave_any(active)) break;
         words8 w0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) w0.w[i] = r0[i];
-        int d = bitlen256(w0) - bl1;
-        d = (active && d > 0) ? d : 0;
+        // leading 63 bits of r0 and of r1, each at its own position: r0 >= A * 2^p0 and r1 < (B + 1) * 2^p1,
+        // so r0 / r1 > A / (B + 1) * 2^(p0 - p1)
+        const int p0 = bitlen256(w0) - 63, p1 = bitlen256(w1) - 63;
+        const uint64_t A = bits64_at(r0, p0), B = bits64_at(r1, p1);
+        const int e = active ? p0 - p1 : 0;                       // >= 0 because r0 >= r1
+        double qd = ((double)A / ((double)B + 1.0)) * (1.0 - 1.0 / 1125899906842624.0);   // in (0.49, 2)
+        // A quotient of 2^31 or more (adversarial c only) is taken as q * 2^k with q below 2^31: the
+        // multiple removed is q * (r1 << k).  The shifter runs only when some lane of the wave needs it.
         uint32_t x[8], y[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = r1[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = t1[i];
-        if (wave_any(d >= 32)) {          // rare: a huge partial quotient somewhere in the wave
-            shl_words(x, d & ~31);
-            shl_words(y, d & ~31);
+        const int k = e > 30 ? e - 30 : 0;
+        qd = qd * (double)(1u << (e - k));                        // * 2^min(e, 30)
+        if (wave_any(k > 0)) {
+            shl_words(x, k);
+            shl_words(y, k);
         }
-        shl_bits(x, d & 31);
-        shl_bits(y, d & 31);
-        if (lt_words(r0, x)) { shr1_words(x); shr1_words(y); }   // only possible when d >= 1
+        uint32_t q = (uint32_t)qd;
+        q = q ? q : 1u;                       // r0 >= r1 always, so one multiple can be removed
+        q = active ? q : 0u;
+        // r0 -= q * x ; t0 += q * y
         uint32_t n0[8], m0[4];
-        uint32_t borrow = 0, carry = 0;
+        uint64_t carry = 0;
+        uint32_t borrow = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            uint64_t t = (uint64_t)r0[i] - x[i] - borrow;
-            n0[i] = (uint32_t)t;
-            borrow = (uint32_t)(t >> 63);
+            carry += (uint64_t)q * x[i];
+            uint64_t d = (uint64_t)r0[i] - (uint32_t)carry - borrow;
+            n0[i] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+            carry >>= 32;
+        }
+        carry = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            carry += (uint64_t)q * y[i] + t0[i];
+            m0[i] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        const bool swap = active && lt_words(n0, r1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t a = n0[i], b = r1[i];
+            r0[i] = swap ? b : a;
+            r1[i] = swap ? a : b;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint64_t t = (uint64_t)t0[i] + y[i] + carry;
-            m0[i] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
+            const uint32_t a = m0[i], b = t1[i];
+            t0[i] = swap ? b : a;
+            t1[i] = swap ? a : b;
         }
-        const bool swap = lt_words(n0, r1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint32_t nr0 = swap ? r1[i] : n0[i], nr1 = swap ? n0[i] : r1[i];
-            r0[i] = active ? nr0 : r0[i];
-            r1[i] = active ? nr1 : r1[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t nt0 = swap ? t1[i] : m0[i], nt1 = swap ? m0[i] : t1[i];
-            t0[i] = active ? nt0 : t0[i];
-            t1[i] = active ? nt1 : t1[i];
-        }
-        neg = (active && swap) ? !neg : neg;
+        neg = swap ? !neg : neg;
     }
     half_scalars h;
 #pragma unroll
