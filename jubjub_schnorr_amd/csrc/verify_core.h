@@ -222,9 +222,9 @@ JJS_HD words8 fr_sub_mul(const words8& a, const words8& b, const words8& c) {
 // For the challenge c find a, b with  a = b*c (mod r),  0 <= a < 2^126,  0 < |b| < 2^126, by running
 // Euclid on (r, c) until the remainder drops below 2^126.  Then, for points of order r,
 //     u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O      (b is invertible mod r),
-// which needs 126 shared doublings instead of 252.  The Euclid steps are taken one aligned
-// subtraction at a time (r0 -= r1 << k with r1 << k <= r0 < r1 << (k+1)), so every lane runs the same
-// loop body; lanes that have finished idle until the slowest lane of the wave is done.
+// which needs 126 shared doublings instead of 252.  The Euclid passes use partial quotients estimated in
+// double precision (half_size_scalars below); every lane runs the same loop body and lanes that have
+// finished idle until the slowest lane of the wave is done.
 struct u128w {
     uint32_t w[4];
 };
@@ -263,19 +263,6 @@ JJS_HD void shl_words(uint32_t (&x)[N], int d) {
         uint64_t v = ((uint64_t)x[i] << 32) | (i ? x[i - 1] : 0u);
         x[i] = (uint32_t)((v << bs) >> 32);
     }
-}
-template <int N>
-JJS_HD void shl_bits(uint32_t (&x)[N], int bs) {   // 0 <= bs < 32
-#pragma unroll
-    for (int i = N - 1; i >= 0; --i) {
-        uint64_t v = ((uint64_t)x[i] << 32) | (i ? x[i - 1] : 0u);
-        x[i] = (uint32_t)((v << bs) >> 32);
-    }
-}
-template <int N>
-JJS_HD void shr1_words(uint32_t (&x)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (x[i] >> 1) | (i + 1 < N ? x[i + 1] << 31 : 0u);
 }
 template <int N>
 JJS_HD bool lt_words(const uint32_t (&a)[N], const uint32_t (&b)[N]) {  // a < b
