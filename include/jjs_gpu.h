@@ -36,7 +36,9 @@
  * tables, workspace and stream between jjs_init and jjs_shutdown.
  *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
- * thread and are serialised by one internal mutex (one batch in flight per process).
+ * thread and are serialised by one internal mutex.  The *_dev calls are asynchronous, but because they
+ * share the engine's workspaces the library orders them on the device (each launch waits for the
+ * previous one, also across streams): one batch in flight per process.
  */
 #ifndef JJS_GPU_H
 #define JJS_GPU_H

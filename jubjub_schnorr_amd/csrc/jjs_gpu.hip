@@ -160,6 +160,7 @@ struct engine {
     unsigned long long* tally = nullptr;
     int grid_verify = 0, grid_sign = 0;
     size_t ws_lanes = 0;
+    hipEvent_t last_use = nullptr;  // end of the last launch that used the shared workspaces
     uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
     uint8_t* dlog_hash = nullptr;
     uint32_t* tags_long = nullptr; // SAFE tags for long transcripts (multisig)
@@ -196,12 +197,24 @@ int grid_for(int resident, size_t n) {
 
 uint32_t g_skip_phases = 0;   // set by jjs_debug_skip_phases (profiling ablations only)
 
+// The per-lane workspace, the wire and the multisig scratch are shared by every call, so launches issued
+// on different streams are ordered one after the other on the device: each waits for the previous user.
+int begin_shared(hipStream_t s) {
+    HIP_TRY(hipStreamWaitEvent(s, g.last_use, 0));
+    return JJS_OK;
+}
+int end_shared(hipStream_t s) {
+    HIP_TRY(hipEventRecord(g.last_use, s));
+    return JJS_OK;
+}
+
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
     P.skip_phases = g_skip_phases;
+    if (int rc = begin_shared(s)) return rc;
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g.grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
-    return JJS_OK;
+    return end_shared(s);
 }
 
 int check_ready() { return g.ready ? JJS_OK : fail(JJS_ERR_NOT_INIT, "jjs_init has not been called"); }
@@ -254,6 +267,8 @@ int jjs_init(int device_count) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, g.device));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.last_use, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g.last_use, g.stream));
     int per_cu_v = 0, per_cu_s = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
@@ -300,6 +315,7 @@ void jjs_shutdown(void) {
     g.msig = nullptr; g.msig_items = g.msig_transcripts = 0;
     (void)hipFree(g.tags_long); g.tags_long = nullptr;
     (void)hipFree(g.dlog_pow); (void)hipFree(g.dlog_hash); g.dlog_pow = nullptr; g.dlog_hash = nullptr;
+    (void)hipEventDestroy(g.last_use); g.last_use = nullptr;
     (void)hipStreamDestroy(g.stream);
     g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
     g.ready = false;
@@ -414,11 +430,12 @@ static uint8_t* wire_bad() { return g.wire + (size_t)4 * g.wire_items * 64; }
 
 static int launch_decode(decode_params D, hipStream_t s) {
     D.dlog = dlog_tables{g.dlog_pow, g.dlog_hash};
+    if (int rc = begin_shared(s)) return rc;
     size_t blocks = (D.n + BLOCK - 1) / BLOCK;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, D);
     HIP_TRY(hipGetLastError());
-    return JJS_OK;
+    return end_shared(s);
 }
 
 static int wire_single_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
@@ -428,6 +445,7 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
     if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
     D.n_src = 2; D.n = n; D.bad = wire_bad();
@@ -447,6 +465,7 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
     if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
     D.n_src = 4; D.n = n; D.bad = wire_bad();
@@ -469,6 +488,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
     if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
     D.n_src = 3; D.n = n; D.bad = wire_bad();
@@ -574,13 +594,14 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     uint32_t* d_off = w;
     P.offsets = d_off;
     P.tags = g.tags_long; P.comb_g = g.comb_g; P.lane_ws = g.workspace;
+    if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     for (int pass = 0; pass < 6; ++pass) {
         const size_t count = (pass == 0 || pass == 2 || pass == 4) ? n_transcripts : n;
         hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g.grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
     }
     HIP_TRY(hipGetLastError());
-    return JJS_OK;
+    return end_shared(s);
 }
 
 // ---- challenge export ---------------------------------------------------------------------------
@@ -634,9 +655,10 @@ static int launch_sign(sign_params P, void* stream) {
     if (P.n == 0) return JJS_OK;
     hipStream_t s = (hipStream_t)stream;
     P.comb_g = g.comb_g; P.comb_gn = g.comb_gn; P.workspace = g.workspace;
+    if (int rc = begin_shared(s)) return rc;
     hipLaunchKernelGGL(sign_kernel, dim3(grid_for(g.grid_sign, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
-    return JJS_OK;
+    return end_shared(s);
 }
 int jjs_sign_single_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out, void* PK_out,
                         void* stream) {

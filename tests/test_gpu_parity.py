@@ -348,3 +348,24 @@ def test_differential_32k_against_c_oracle(eng, scheme):
     canonical = want != 3          # the oracle exports a challenge only for canonical inputs
     assert (host(c)[canonical] == want_c[canonical]).all()
     assert set(want.tolist()) == {0, 1, 2, 3}
+
+
+def test_calls_on_different_streams_do_not_interfere(eng):
+    """The engine's workspaces are shared; launches from different streams must be ordered by the library."""
+    import torch
+    batches = [make_batch("single", 20000, seed=900 + i, n_keys=32) for i in range(2)] + [make_batch("vargen", 20000, seed=950, n_keys=32)]
+    schemes = ["single", "single", "vargen"]
+    args = [[dev(b[k]) for k in ARG_ORDER[s]] for b, s in zip(batches, schemes)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in batches]
+    outs = []
+    for _ in range(3):                       # interleave launches on three streams, several rounds
+        outs = []
+        for a, s, st in zip(args, schemes, streams):
+            with torch.cuda.stream(st):
+                outs.append(eng.verify(s, *a))
+    torch.cuda.synchronize()
+    for (st, tally), b, s in zip(outs, batches, schemes):
+        want = oracle_verify(s, b)
+        assert host(st).tolist() == want.tolist()
+        assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
