@@ -125,6 +125,11 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
     st = fn(*[host[k] for k in ARG_ORDER[scheme]], threads=threads, native=native)
     dt = time.perf_counter() - t0
     agree = bool((st == gpu_status[:n].cpu().numpy()).all())
+    # BASELINE.json configs[0]: 1 024 signatures on one CPU thread
+    k1 = min(n, 1024)
+    t1 = time.perf_counter()
+    fn(*[host[x][:k1] for x in ARG_ORDER[scheme]], threads=1, native=native)
+    one_thread = k1 / (time.perf_counter() - t1)
     c_agree = None
     if gpu_challenge is not None:      # every debug challenge equal on a 2^16 sample
         k = min(n, 1 << 16)
@@ -134,6 +139,7 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
     return {"value": n / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
             "sample": f"first {n} items of the same {scheme} batch, oracle/jjs_oracle.c "
                       f"({'-march=native' if native else 'generic x86-64'}), {dt:.1f} s",
+            "one_thread": {"value": one_thread, "items": k1},
             "statuses_equal_gpu": agree, "challenges_equal_gpu_on_2^16_sample": c_agree}
 
 
