@@ -146,6 +146,7 @@ JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& s
     int d = (w == top) ? (int)nib : (int)nib - 8;
     bool neg = d < 0;
     uint32_t idx = (uint32_t)(neg ? -d : d);
+    idx = idx > 8u ? 8u : idx;    // only an out-of-range (malformed, status 3) scalar gets here: stay inside the table
     return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg != flip, need_t);
 }
 
