@@ -507,23 +507,4 @@ JJS_HD fe_n fq_pow_schedule(const fe_n& a, const uint32_t (*sched)[2], int steps
     for (int j = 0; j < trailing; ++j) e = fq_sqr(e);
     return e;
 }
-// x == 1 for a product output (normalised limbs, value < 2q): two possible representatives
-JJS_HD bool fq_is_one_weak(const fe_n& x) {
-    uint32_t d0 = 0, d1 = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { d0 |= x.l[i] ^ JJS_ONE[i]; d1 |= x.l[i] ^ JJS_ONE_PLUS_Q[i]; }
-    return d0 == 0 || d1 == 0;
-}
-
-// a^e for a public exponent (wave-uniform control flow), MSB first; e as 32-bit words
-template <int A>
-JJS_HD fe_n fq_pow_public(const fe<1, A>& a, const uint32_t* e, int nbits) {
-    fe_n acc = fq_as<1, 2>(fq_one());
-    for (int i = nbits - 1; i >= 0; --i) {
-        acc = fq_sqr(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = fq_mul(acc, a);
-    }
-    return acc;
-}
-
 }  // namespace jjs

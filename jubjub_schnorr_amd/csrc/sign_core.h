@@ -21,17 +21,8 @@ struct sign_params {
 };
 
 // ---- scalar multiplications --------------------------------------------------------------------
-JJS_HD ext_pt comb_mul(const uint32_t* comb, const words8& k) {
-    ext_pt acc = ext_identity();
-    for (int i = 0; i < COMB_WINDOWS; ++i) {
-        uint32_t byte = (word_at(k, i >> 2) >> ((i & 3) * 8)) & 255u;
-        const uint32_t* e = comb + ((size_t)i * COMB_ENTRIES + byte) * COMB_ENTRY_WORDS;
-        fe_t ypx, ymx, t2d;
-        for (int j = 0; j < 9; ++j) { ypx.l[j] = e[j]; ymx.l[j] = e[9 + j]; t2d.l[j] = e[18 + j]; }
-        acc = ext_add_affine_niels(acc, ypx, ymx, t2d, true);
-    }
-    return acc;
-}
+// k * Base from the fixed-base comb table (T of the result is not valid: callers only normalise it)
+JJS_HD ext_pt comb_mul(const uint32_t* comb, const words8& k) { return add_comb(ext_identity(), comb, k); }
 // k * P for the table of P built by build_point_table; k < 2^252.  T is only valid when final_t is set.
 JJS_HD ext_pt table_mul(const uint32_t* tab, const words8& k, bool final_t = false) {
     const words8 sk = recode_signed4(k);

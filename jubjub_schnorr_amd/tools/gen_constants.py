@@ -357,7 +357,6 @@ def main():
     L.append("#define JJS_DLOG_HASH_MULT %du" % mult)
     L.append("#define JJS_DLOG_HASH_SHIFT %d" % shift)
     L.append("JJS_CONST uint32_t JJS_ROOT_OF_UNITY[9] = %s;  // 7^((q-1)/2^32): generator of the 2^32-torsion of Fq*" % limbs29(mont(zeta)))
-    L.append("JJS_CONST uint32_t JJS_ONE_PLUS_Q[9] = %s;  // the other representative of 1 below 2q" % limbs29(MONT + Q))
     L.append("JJS_CONST uint32_t JJS_RC[%d][9] = {" % len(rc))
     L += ["  %s," % limbs29(mont(c)) for c in rc]
     L.append("};")
