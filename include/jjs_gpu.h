@@ -33,12 +33,12 @@
  *
  * Ownership: the caller owns every buffer passed in; the library keeps nothing after a blocking
  * call returns (after the stream has drained, for the *_dev calls).  The library owns its device
- * tables, workspace and stream between jjs_init and jjs_shutdown.
+ * tables, workspaces, streams and RCCL communicators between jjs_init and jjs_shutdown.
  *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
  * thread and are serialised by one internal mutex.  The *_dev calls are asynchronous, but because they
  * share the engine's workspaces the library orders them on the device (each launch waits for the
- * previous one, also across streams): one batch in flight per process.
+ * previous one on the same device, also across streams): one batch in flight per device.
  */
 #ifndef JJS_GPU_H
 #define JJS_GPU_H
@@ -61,12 +61,21 @@ extern "C" {
 #define JJS_STATUS_INVALID_SIGNATURE 2
 #define JJS_STATUS_MALFORMED 3
 
-/* Binds the engine to the calling thread's current HIP device (one process per GPU), builds the
- * fixed-base tables for G and G' on it and allocates the workspace.  `device_count` must be 0 or 1
- * in this version (multi-GPU = one process per GPU, batches sharded by the caller, see
- * INTEGRATION.md).  Idempotent. */
+/* Sets up the devices this process drives: builds the fixed-base tables for G and G' on each, allocates
+ * the per-lane workspaces and one stream per device.
+ *   device_count == 1 : the calling thread's current HIP device only (one process per GPU: what a
+ *                       torch.distributed / torchrun rank uses);
+ *   device_count == k : HIP devices 0 .. k-1 in this one process (2 <= k <= 16);
+ *   device_count == 0 : every visible HIP device.
+ * With several devices the host-buffer calls below cut each batch into one contiguous block of
+ * ceil(n / devices) items per device, run the blocks concurrently and sum the four tally counters with
+ * one RCCL all-reduce (4 x u64, the only collective; RCCL is loaded on demand and not at all for one
+ * device).  The *_dev calls always act on the calling thread's current device, which must be one of the
+ * devices set up here.  Idempotent for a repeated identical request. */
 int jjs_init(int device_count);
 void jjs_shutdown(void);
+/* Number of devices the process drives (0 before jjs_init). */
+int jjs_device_count(void);
 const char* jjs_last_error(void);
 /* ABI version: bumped on any signature change. */
 int jjs_abi_version(void);
@@ -161,6 +170,9 @@ int jjs_debug_skip_phases(unsigned mask);
  * jjs_debug_comb_table_bytes() */
 size_t jjs_debug_comb_table_bytes(void);
 int jjs_debug_comb_table(int which, void* host_out);
+/* Loads RCCL, forms a one-rank clique on the current device and all-reduces a known 4 x u64 vector on the
+ * engine stream: the call sequence of the multi-device tally reduction, runnable with a single GPU. */
+int jjs_debug_rccl_selftest(void);
 
 #ifdef __cplusplus
 }

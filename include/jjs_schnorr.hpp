@@ -56,10 +56,12 @@ struct EngineError : std::runtime_error {
     EngineError(int c, const char* what) : std::runtime_error(std::string(what) + ": " + jjs_last_error()), code(c) {}
 };
 
-// RAII handle on the process-wide engine (jjs_init binds to the current HIP device).
+// RAII handle on the process-wide engine: device_count 1 = the current HIP device, k = devices 0..k-1,
+// 0 = every visible device (batches of the host-buffer calls are then sharded across them).
 class Engine {
   public:
-    Engine() { int rc = jjs_init(0); if (rc != JJS_OK) throw EngineError(rc, "jjs_init"); }
+    explicit Engine(int device_count = 1) { int rc = jjs_init(device_count); if (rc != JJS_OK) throw EngineError(rc, "jjs_init"); }
+    int device_count() const { return jjs_device_count(); }
     ~Engine() { jjs_shutdown(); }
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;

@@ -18,6 +18,7 @@ SIGNATURES = {
     "jjs_shutdown": [],
     "jjs_last_error": [],
     "jjs_abi_version": [],
+    "jjs_device_count": [],
     "jjs_verify_single": [_P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_double": [_P, _P, _P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_vargen": [_P, _P, _P, _P, _P, _Z, _P, _P],
@@ -46,6 +47,7 @@ SIGNATURES = {
     "jjs_debug_skip_phases": [ctypes.c_uint],
     "jjs_debug_comb_table_bytes": [],
     "jjs_debug_comb_table": [_I, _P],
+    "jjs_debug_rccl_selftest": [],
 }
 _RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
 

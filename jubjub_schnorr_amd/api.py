@@ -53,9 +53,11 @@ def _is_torch(x) -> bool:
 
 
 class Engine:
-    """One engine per process, bound to the current HIP device (one process per GPU)."""
+    """One engine per process.  `device_count=1` (default) binds it to the current HIP device -- one process
+    per GPU, what a torch.distributed rank uses; `device_count=k` drives devices 0..k-1 and 0 every visible
+    device from this one process: the numpy (host-buffer) calls are then sharded across them by the library."""
 
-    def __init__(self):
+    def __init__(self, device_count: int = 1):
         # When PyTorch shares the process, let it bring up the HIP runtime first: torch ships its own
         # libamdhip64 and fails with "No HIP GPUs are available" if another copy initialised the device
         # before it (observed on ROCm 7.2 / torch 2.10).
@@ -66,7 +68,8 @@ class Engine:
         except ImportError:
             pass
         self._lib = _ffi.lib()
-        _ffi.check(self._lib.jjs_init(0), "jjs_init")
+        _ffi.check(self._lib.jjs_init(int(device_count)), "jjs_init")
+        self.device_count = self._lib.jjs_device_count()
 
     # ---- helpers ------------------------------------------------------------------------------
     @staticmethod
@@ -260,10 +263,10 @@ class Engine:
 _engine = None
 
 
-def engine() -> Engine:
+def engine(device_count: int = 1) -> Engine:
     global _engine
     if _engine is None:
-        _engine = Engine()
+        _engine = Engine(device_count)
     return _engine
 
 

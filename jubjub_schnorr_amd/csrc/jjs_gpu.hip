@@ -9,7 +9,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
+#include <vector>
+
+#include <rccl/rccl.h>
 
 #include "../../include/jjs_gpu.h"
 #include "schemes.h"
@@ -149,10 +153,10 @@ __global__ __launch_bounds__(BLOCK) void dbg_point_flags_kernel(const uint8_t* p
 }
 
 // ---------------------------------------------------------------------------------------------
-struct engine {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
+// Per-device state: everything a launch on that device needs (tables, per-lane workspace, scratch).
+struct device_state {
+    int device = -1;               // HIP device ordinal
+    hipStream_t stream = nullptr;  // used by the host-buffer entry points
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
     uint8_t* tag = nullptr;
@@ -169,15 +173,37 @@ struct engine {
     int grid_msig = 0;
     uint8_t* wire = nullptr;       // decoded points (4 x n x 64) + flags (n) for the *_wire entry points
     size_t wire_items = 0;
+};
+
+// RCCL is needed only when one process drives several devices, so it is loaded on demand.
+struct rccl_api {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+constexpr int MAX_DEVICES = 16;
+
+struct library_state {
     std::mutex mu;
     char err[512] = "";
+    std::vector<device_state*> devs;       // devices this process drives (jjs_init)
+    bool virtual_devices = false;          // test mode: several logical devices on one physical device
+    rccl_api rccl;
+    ncclComm_t comms[MAX_DEVICES] = {};
+    bool comms_up = false;
 };
-engine g;
+library_state L;
+device_state* g = nullptr;   // device bound to the call in progress (set under L.mu by bind_device)
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g.err, sizeof(g.err), fmt, ap);
+    vsnprintf(L.err, sizeof(L.err), fmt, ap);
     va_end(ap);
     return code;
 }
@@ -185,6 +211,11 @@ int fail(int code, const char* fmt, ...) {
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
         if (e_ != hipSuccess) return fail(JJS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+#define RCCL_TRY(x)                                                                                      \
+    do {                                                                                                 \
+        ncclResult_t r_ = (x);                                                                           \
+        if (r_ != ncclSuccess) return fail(JJS_ERR_COLLECTIVE, "%s: %s", #x, L.rccl.GetErrorString(r_)); \
     } while (0)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -200,11 +231,11 @@ uint32_t g_skip_phases = 0;   // set by jjs_debug_skip_phases (profiling ablatio
 // The per-lane workspace, the wire and the multisig scratch are shared by every call, so launches issued
 // on different streams are ordered one after the other on the device: each waits for the previous user.
 int begin_shared(hipStream_t s) {
-    HIP_TRY(hipStreamWaitEvent(s, g.last_use, 0));
+    HIP_TRY(hipStreamWaitEvent(s, g->last_use, 0));
     return JJS_OK;
 }
 int end_shared(hipStream_t s) {
-    HIP_TRY(hipEventRecord(g.last_use, s));
+    HIP_TRY(hipEventRecord(g->last_use, s));
     return JJS_OK;
 }
 
@@ -212,12 +243,21 @@ int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
     P.skip_phases = g_skip_phases;
     if (int rc = begin_shared(s)) return rc;
-    hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g.grid_verify, P.n)), dim3(BLOCK), 0, s, P);
+    hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
     return end_shared(s);
 }
 
-int check_ready() { return g.ready ? JJS_OK : fail(JJS_ERR_NOT_INIT, "jjs_init has not been called"); }
+// Every entry point works on the calling thread's current HIP device, which must be one jjs_init set up.
+int check_ready() {
+    if (L.devs.empty()) return fail(JJS_ERR_NOT_INIT, "jjs_init has not been called");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    for (device_state* d : L.devs)
+        if (d->device == dev) { g = d; return JJS_OK; }
+    return fail(JJS_ERR_NOT_INIT, "the current HIP device (%d) is not one of the %zu this process initialised", dev,
+                L.devs.size());
+}
 
 template <typename... Ptrs>
 bool all_ok(Ptrs... p) {
@@ -242,12 +282,183 @@ struct staged {
     int alloc(size_t bytes) { HIP_TRY(hipMalloc(&d, bytes ? bytes : 16)); return JJS_OK; }
 };
 
-int finish_host(staged& st, uint8_t* status, uint64_t tally[4], size_t n) {
-    if (status && n) HIP_TRY(hipMemcpyAsync(status, st.d, n, hipMemcpyDeviceToHost, g.stream));
-    unsigned long long t[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(t, g.tally, sizeof(t), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+int init_device(device_state& d, int ordinal) {
+    d.device = ordinal;
+    HIP_TRY(hipSetDevice(ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+    HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.last_use, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(d.last_use, d.stream));
+    int per_cu_v = 0, per_cu_s = 0, per_cu_m = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_m, msig_kernel, BLOCK, 0));
+    if (per_cu_v < 1) per_cu_v = 1;
+    if (per_cu_s < 1) per_cu_s = 1;
+    if (per_cu_m < 1) per_cu_m = 1;
+    d.grid_verify = prop.multiProcessorCount * per_cu_v;
+    d.grid_sign = prop.multiProcessorCount * per_cu_s;
+    d.grid_msig = prop.multiProcessorCount * per_cu_m;
+    int lanes_blocks = d.grid_verify > d.grid_sign ? d.grid_verify : d.grid_sign;
+    if (d.grid_msig > lanes_blocks) lanes_blocks = d.grid_msig;
+    d.ws_lanes = (size_t)lanes_blocks * BLOCK;
+    HIP_TRY(hipMalloc(&d.workspace, d.ws_lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d.tag, 32));
+    HIP_TRY(hipMalloc(&d.tally, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&d.dlog_pow, DLOG_POW_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d.dlog_hash, 65536));
+    HIP_TRY(hipMemsetAsync(d.dlog_hash, 0, 65536, d.stream));
+    hipLaunchKernelGGL(dlog_table_kernel, dim3(7), dim3(BLOCK), 0, d.stream, d.dlog_pow, d.dlog_hash);
+    HIP_TRY(hipMalloc(&d.tags_long, sizeof(JJS_SPONGE_TAG_LONG)));
+    HIP_TRY(hipMemcpyAsync(d.tags_long, JJS_SPONGE_TAG_LONG, sizeof(JJS_SPONGE_TAG_LONG), hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipMemcpyAsync(d.tag, JJS_DOUBLE_TAG_WORDS, 32, hipMemcpyHostToDevice, d.stream));
+    const int blocks = (COMB_WINDOWS * COMB_ENTRIES + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, d.stream, d.comb_g, 0);
+    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, d.stream, d.comb_gn, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return JJS_OK;
+}
+
+void free_device(device_state& d) {
+    if (d.device < 0) return;
+    (void)hipSetDevice(d.device);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (d.last_use) (void)hipEventDestroy(d.last_use);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    d = device_state{};
+}
+
+int load_rccl() {
+    rccl_api& r = L.rccl;
+    if (r.handle) return JJS_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(JJS_ERR_COLLECTIVE, "cannot load RCCL: %s", dlerror());
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        dlclose(h);
+        r = rccl_api{};
+        return fail(JJS_ERR_COLLECTIVE, "RCCL library lacks a required symbol");
+    }
+    r.handle = h;
+    return JJS_OK;
+}
+
+// One communicator per driven device, all in this process (ranks = positions in L.devs).
+int start_comms() {
+    if (int rc = load_rccl()) return rc;
+    int ords[MAX_DEVICES];
+    for (size_t i = 0; i < L.devs.size(); ++i) ords[i] = L.devs[i]->device;
+    RCCL_TRY(L.rccl.CommInitAll(L.comms, (int)L.devs.size(), ords));
+    L.comms_up = true;
+    return JJS_OK;
+}
+
+// Sum of the 4-counter tallies over the driven devices, in place in every device's buffer; queued on each
+// device's stream behind the launch that produced the counters (the only collective).
+int allreduce_tallies() {
+    RCCL_TRY(L.rccl.GroupStart());
+    for (size_t i = 0; i < L.devs.size(); ++i) {
+        device_state& d = *L.devs[i];
+        ncclResult_t r = L.rccl.AllReduce(d.tally, d.tally, 4, ncclUint64, ncclSum, L.comms[i], d.stream);
+        if (r != ncclSuccess) {
+            (void)L.rccl.GroupEnd();
+            return fail(JJS_ERR_COLLECTIVE, "ncclAllReduce: %s", L.rccl.GetErrorString(r));
+        }
+    }
+    RCCL_TRY(L.rccl.GroupEnd());
+    return JJS_OK;
+}
+
+void shutdown_locked() {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (device_state* d : L.devs)
+        if (d->stream) { (void)hipSetDevice(d->device); (void)hipStreamSynchronize(d->stream); }
+    if (L.comms_up) {
+        for (size_t i = 0; i < L.devs.size(); ++i) (void)L.rccl.CommDestroy(L.comms[i]);
+        L.comms_up = false;
+    }
+    for (device_state* d : L.devs) { free_device(*d); delete d; }
+    L.devs.clear();
+    L.virtual_devices = false;
+    g = nullptr;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+struct device_restore {   // puts the calling thread back on the device it came in with
+    int prev = -1;
+    device_restore() { (void)hipGetDevice(&prev); }
+    ~device_restore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Host-buffer calls: the batch is cut into one contiguous block of ceil(n / devices) items per driven
+// device (the rule of jubjub_schnorr_amd/sharding.py), each block is staged, verified and copied back on
+// its device's stream, and the tallies are summed with one RCCL all-reduce.  With one device this is
+// stage -> launch -> copy back.
+struct host_col { const uint8_t* p; size_t width; };
+
+template <size_t K, typename Launch>
+int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tally[4], Launch&& launch) {
+    for (size_t k = 0; k < K; ++k)
+        if (n && !cols[k].p) return fail(JJS_ERR_ARG, "null input pointer");
+    std::vector<device_state*> targets;
+    if (L.devs.size() == 1) targets.push_back(g); else targets = L.devs;
+    const size_t nd = targets.size();
+    struct block { staged in[K]; staged st; size_t lo = 0, hi = 0; };
+    std::vector<block> blocks(nd);
+    device_restore restore;
+    const size_t per = (n + nd - 1) / nd;
+    int rc;
+    for (size_t d = 0; d < nd; ++d) {
+        g = targets[d];
+        HIP_TRY(hipSetDevice(g->device));
+        block& b = blocks[d];
+        b.lo = d * per < n ? d * per : n;
+        b.hi = b.lo + per < n ? b.lo + per : n;
+        const size_t nl = b.hi - b.lo;
+        const void* dp[K];
+        for (size_t k = 0; k < K; ++k) {
+            if ((rc = b.in[k].up(cols[k].p ? cols[k].p + b.lo * cols[k].width : nullptr, nl * cols[k].width, g->stream))) return rc;
+            dp[k] = b.in[k].d;
+        }
+        if ((rc = b.st.alloc(nl))) return rc;
+        if ((rc = launch(dp, nl, b.st.d, (void*)g->tally, (void*)g->stream))) return rc;
+    }
+    if (nd > 1 && L.comms_up)
+        if ((rc = allreduce_tallies())) return rc;
+    unsigned long long t[MAX_DEVICES][4] = {};
+    for (size_t d = 0; d < nd; ++d) {
+        g = targets[d];
+        HIP_TRY(hipSetDevice(g->device));
+        const block& b = blocks[d];
+        if (status && b.hi > b.lo)
+            HIP_TRY(hipMemcpyAsync(status + b.lo, b.st.d, b.hi - b.lo, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipMemcpyAsync(t[d], g->tally, sizeof(t[d]), hipMemcpyDeviceToHost, g->stream));
+    }
+    for (size_t d = 0; d < nd; ++d) {
+        HIP_TRY(hipSetDevice(targets[d]->device));
+        HIP_TRY(hipStreamSynchronize(targets[d]->stream));
+    }
+    if (tally) {
+        for (int i = 0; i < 4; ++i) tally[i] = t[0][i];
+        // test mode (logical devices sharing one GPU cannot form an RCCL clique): add the counters here
+        if (nd > 1 && !L.comms_up)
+            for (size_t d = 1; d < nd; ++d)
+                for (int i = 0; i < 4; ++i) tally[i] += t[d][i];
+    }
     return JJS_OK;
 }
 
@@ -255,74 +466,54 @@ int finish_host(staged& st, uint8_t* status, uint64_t tally[4], size_t n) {
 
 extern "C" {
 
-int jjs_abi_version(void) { return 1; }
-const char* jjs_last_error(void) { return g.err; }
+int jjs_abi_version(void) { return 2; }
+const char* jjs_last_error(void) { return L.err; }
 
 int jjs_init(int device_count) {
-    std::lock_guard<std::mutex> lock(g.mu);
-    if (device_count != 0 && device_count != 1)
-        return fail(JJS_ERR_ARG, "this version drives one device per process (got device_count=%d)", device_count);
-    if (g.ready) return JJS_OK;
-    HIP_TRY(hipGetDevice(&g.device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g.last_use, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(g.last_use, g.stream));
-    int per_cu_v = 0, per_cu_s = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
-    int per_cu_m = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_m, msig_kernel, BLOCK, 0));
-    if (per_cu_m < 1) per_cu_m = 1;
-    g.grid_msig = prop.multiProcessorCount * per_cu_m;
-    if (per_cu_v < 1) per_cu_v = 1;
-    if (per_cu_s < 1) per_cu_s = 1;
-    g.grid_verify = prop.multiProcessorCount * per_cu_v;
-    g.grid_sign = prop.multiProcessorCount * per_cu_s;
-    int lanes_blocks = g.grid_verify > g.grid_sign ? g.grid_verify : g.grid_sign;
-    if (g.grid_msig > lanes_blocks) lanes_blocks = g.grid_msig;
-    g.ws_lanes = (size_t)lanes_blocks * BLOCK;
-    HIP_TRY(hipMalloc(&g.workspace, g.ws_lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&g.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&g.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&g.tag, 32));
-    HIP_TRY(hipMalloc(&g.tally, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&g.dlog_pow, DLOG_POW_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&g.dlog_hash, 65536));
-    HIP_TRY(hipMemsetAsync(g.dlog_hash, 0, 65536, g.stream));
-    hipLaunchKernelGGL(dlog_table_kernel, dim3(7), dim3(BLOCK), 0, g.stream, g.dlog_pow, g.dlog_hash);
-    HIP_TRY(hipMalloc(&g.tags_long, sizeof(JJS_SPONGE_TAG_LONG)));
-    HIP_TRY(hipMemcpyAsync(g.tags_long, JJS_SPONGE_TAG_LONG, sizeof(JJS_SPONGE_TAG_LONG), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.tag, JJS_DOUBLE_TAG_WORDS, 32, hipMemcpyHostToDevice, g.stream));
-    const int blocks = (COMB_WINDOWS * COMB_ENTRIES + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, g.stream, g.comb_g, 0);
-    hipLaunchKernelGGL(comb_kernel, dim3(blocks), dim3(BLOCK), 0, g.stream, g.comb_gn, 1);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    g.ready = true;
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (device_count < 0 || device_count > MAX_DEVICES)
+        return fail(JJS_ERR_ARG, "device_count must be in [0, %d] (got %d)", MAX_DEVICES, device_count);
+    int visible = 0, current = -1;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    HIP_TRY(hipGetDevice(&current));
+    if (visible < 1) return fail(JJS_ERR_HIP, "no HIP device visible");
+    const char* virt = getenv("JJS_DEBUG_VIRTUAL_DEVICES");
+    const bool allow_virtual = virt && virt[0] == '1';
+    const int want = device_count == 0 ? visible : device_count;
+    if (!L.devs.empty()) {   // idempotent for the same request
+        if (device_count == 1) return check_ready();
+        if ((size_t)want == L.devs.size()) return JJS_OK;
+        return fail(JJS_ERR_ARG, "already initialised with %zu device(s); call jjs_shutdown first", L.devs.size());
+    }
+    if (want > visible && !allow_virtual)
+        return fail(JJS_ERR_ARG, "device_count=%d but only %d HIP device(s) are visible", want, visible);
+    L.virtual_devices = want > visible;
+    for (int i = 0; i < want; ++i) {
+        device_state* d = new device_state();
+        L.devs.push_back(d);
+        int rc = init_device(*d, device_count == 1 ? current : i % visible);
+        if (rc) { shutdown_locked(); (void)hipSetDevice(current); return rc; }
+    }
+    HIP_TRY(hipSetDevice(current));
+    if (L.devs.size() > 1 && !L.virtual_devices) {
+        int rc = start_comms();
+        if (rc) { shutdown_locked(); return rc; }
+    }
     return JJS_OK;
 }
 
 void jjs_shutdown(void) {
-    std::lock_guard<std::mutex> lock(g.mu);
-    if (!g.ready) return;
-    (void)hipStreamSynchronize(g.stream);
-    (void)hipFree(g.workspace); (void)hipFree(g.comb_g); (void)hipFree(g.comb_gn); (void)hipFree(g.tag); (void)hipFree(g.tally);
-    if (g.wire) (void)hipFree(g.wire);
-    g.wire = nullptr; g.wire_items = 0;
-    if (g.msig) (void)hipFree(g.msig);
-    g.msig = nullptr; g.msig_items = g.msig_transcripts = 0;
-    (void)hipFree(g.tags_long); g.tags_long = nullptr;
-    (void)hipFree(g.dlog_pow); (void)hipFree(g.dlog_hash); g.dlog_pow = nullptr; g.dlog_hash = nullptr;
-    (void)hipEventDestroy(g.last_use); g.last_use = nullptr;
-    (void)hipStreamDestroy(g.stream);
-    g.workspace = nullptr; g.comb_g = g.comb_gn = nullptr; g.tag = nullptr; g.tally = nullptr; g.stream = nullptr;
-    g.ready = false;
+    std::lock_guard<std::mutex> lock(L.mu);
+    shutdown_locked();
+}
+
+int jjs_device_count(void) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    return (int)L.devs.size();
 }
 
 int jjs_stream_sync(void* stream) {
-    if (int rc = check_ready()) return rc;
+    if (L.devs.empty()) return fail(JJS_ERR_NOT_INIT, "jjs_init has not been called");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return JJS_OK;
 }
@@ -330,32 +521,32 @@ int jjs_stream_sync(void* stream) {
 // ---- device-buffer entry points --------------------------------------------------------------
 int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
                           void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
     return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
-                                           g.comb_g, o), status, tally, s);
+                                           g->comb_g, o), status, tally, s);
 }
 int jjs_verify_double_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
                           size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
     return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
-                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g.tag, g.comb_g, g.comb_gn, o),
+                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o),
                              status, tally, s);
 }
 int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
                           void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
     return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
                                            (const uint8_t*)m, n, o), status, tally, s);
 }
@@ -363,73 +554,57 @@ int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const vo
 // ---- host-buffer entry points ----------------------------------------------------------------
 int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                       uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && (!u || !R || !PK || !m)) return fail(JJS_ERR_ARG, "null input pointer");
-    staged du, dR, dPK, dm, dst;
-    int rc;
-    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dPK.up(PK, 64 * n, g.stream)) ||
-        (rc = dm.up(m, 32 * n, g.stream)) || (rc = dst.alloc(n)))
-        return rc;
-    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
-    if ((rc = verify_dev_common(params_single((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dPK.d, (uint8_t*)dm.d, n, g.comb_g, o),
-                                dst.d, g.tally, g.stream)))
-        return rc;
-    return finish_host(dst, status, tally, n);
+    const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
+        return verify_dev_common(params_single((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
+                                               (const uint8_t*)d[3], nl, g->comb_g, o), st, tl, (hipStream_t)s);
+    });
 }
 int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
                       const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && (!u || !R || !Rp || !PK || !PKp || !m)) return fail(JJS_ERR_ARG, "null input pointer");
-    staged du, dR, dRp, dPK, dPKp, dm, dst;
-    int rc;
-    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dRp.up(Rp, 64 * n, g.stream)) ||
-        (rc = dPK.up(PK, 64 * n, g.stream)) || (rc = dPKp.up(PKp, 64 * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) ||
-        (rc = dst.alloc(n)))
-        return rc;
-    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
-    if ((rc = verify_dev_common(params_double((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dRp.d, (uint8_t*)dPK.d,
-                                              (uint8_t*)dPKp.d, (uint8_t*)dm.d, n, g.tag, g.comb_g, g.comb_gn, o),
-                                dst.d, g.tally, g.stream)))
-        return rc;
-    return finish_host(dst, status, tally, n);
+    const host_col cols[] = {{u, 32}, {R, 64}, {Rp, 64}, {PK, 64}, {PKp, 64}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
+        return verify_dev_common(params_double((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
+                                               (const uint8_t*)d[3], (const uint8_t*)d[4], (const uint8_t*)d[5], nl,
+                                               g->tag, g->comb_g, g->comb_gn, o), st, tl, (hipStream_t)s);
+    });
 }
 int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
                       size_t n, uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && (!u || !R || !PK || !Gen || !m)) return fail(JJS_ERR_ARG, "null input pointer");
-    staged du, dR, dPK, dG, dm, dst;
-    int rc;
-    if ((rc = du.up(u, 32 * n, g.stream)) || (rc = dR.up(R, 64 * n, g.stream)) || (rc = dPK.up(PK, 64 * n, g.stream)) ||
-        (rc = dG.up(Gen, 64 * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) || (rc = dst.alloc(n)))
-        return rc;
-    out_ptrs o{(uint8_t*)dst.d, g.tally, nullptr, g.workspace};
-    if ((rc = verify_dev_common(params_vargen((uint8_t*)du.d, (uint8_t*)dR.d, (uint8_t*)dPK.d, (uint8_t*)dG.d,
-                                              (uint8_t*)dm.d, n, o), dst.d, g.tally, g.stream)))
-        return rc;
-    return finish_host(dst, status, tally, n);
+    const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {Gen, 64}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
+        return verify_dev_common(params_vargen((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
+                                               (const uint8_t*)d[3], (const uint8_t*)d[4], nl, o), st, tl, (hipStream_t)s);
+    });
 }
 
 // ---- wire formats: on-device decoding, then the same verify kernel -----------------------------------
 static int ensure_wire(size_t n) {
-    if (n <= g.wire_items) return JJS_OK;
-    if (g.wire) {
+    if (n <= g->wire_items) return JJS_OK;
+    if (g->wire) {
         HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old buffer
-        HIP_TRY(hipFree(g.wire));
-        g.wire = nullptr; g.wire_items = 0;
+        HIP_TRY(hipFree(g->wire));
+        g->wire = nullptr; g->wire_items = 0;
     }
     size_t cap = n < 4096 ? 4096 : n;
-    HIP_TRY(hipMalloc(&g.wire, cap * (4 * 64 + 16)));
-    g.wire_items = cap;
+    HIP_TRY(hipMalloc(&g->wire, cap * (4 * 64 + 16)));
+    g->wire_items = cap;
     return JJS_OK;
 }
-static uint8_t* wire_pts(int k) { return g.wire + (size_t)k * g.wire_items * 64; }
-static uint8_t* wire_bad() { return g.wire + (size_t)4 * g.wire_items * 64; }
+static uint8_t* wire_pts(int k) { return g->wire + (size_t)k * g->wire_items * 64; }
+static uint8_t* wire_bad() { return g->wire + (size_t)4 * g->wire_items * 64; }
 
 static int launch_decode(decode_params D, hipStream_t s) {
-    D.dlog = dlog_tables{g.dlog_pow, g.dlog_hash};
+    D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
     if (int rc = begin_shared(s)) return rc;
     size_t blocks = (D.n + BLOCK - 1) / BLOCK;
     if (blocks > 8192) blocks = 8192;
@@ -440,7 +615,6 @@ static int launch_decode(decode_params D, hipStream_t s) {
 
 static int wire_single_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                               void* stream) {
-    if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
@@ -452,15 +626,14 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
     D.src[1] = fe_src{(const uint8_t*)pk, 32, 0};   D.out[1] = wire_pts(1);      // PK
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
-    verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g.comb_g, o);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
 }
 static int wire_double_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                               void* stream) {
-    if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
@@ -474,16 +647,15 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     D.src[2] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[2] = wire_pts(2);      // PK
     D.src[3] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[3] = wire_pts(3);      // PK'
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
     verify_params P = params_double((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3),
-                                    (const uint8_t*)m, n, g.tag, g.comb_g, g.comb_gn, o);
+                                    (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o);
     P.u = fe_src{(const uint8_t*)sig, 96, 0};
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
 }
 static int wire_vargen_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                               void* stream) {
-    if (int rc = check_ready()) return rc;
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
@@ -496,7 +668,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     D.src[1] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[1] = wire_pts(1);      // PK
     D.src[2] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[2] = wire_pts(2);      // generator
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g.workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
     verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
@@ -505,27 +677,26 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
 typedef int (*wire_fn)(const void*, const void*, const void*, size_t, void*, void*, void*);
 static int wire_host(wire_fn fn, const uint8_t* sig, size_t sig_w, const uint8_t* pk, size_t pk_w, const uint8_t* m, size_t n,
                      uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && (!sig || !pk || !m)) return fail(JJS_ERR_ARG, "null input pointer");
-    staged ds, dp, dm, dst;
-    int rc;
-    if ((rc = ds.up(sig, sig_w * n, g.stream)) || (rc = dp.up(pk, pk_w * n, g.stream)) || (rc = dm.up(m, 32 * n, g.stream)) ||
-        (rc = dst.alloc(n)))
-        return rc;
-    if ((rc = fn(ds.d, dp.d, dm.d, n, dst.d, g.tally, g.stream))) return rc;
-    return finish_host(dst, status, tally, n);
+    const host_col cols[] = {{sig, sig_w}, {pk, pk_w}, {m, 32}};
+    return run_host(cols, n, status, tally, [fn](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        return fn(d[0], d[1], d[2], nl, st, tl, s);
+    });
 }
 int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
     return wire_single_locked(sig, pk, m, n, status, tally, stream);
 }
 int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
     return wire_double_locked(sig, pk, m, n, status, tally, stream);
 }
 int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
     return wire_vargen_locked(sig, pk, m, n, status, tally, stream);
 }
 int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
@@ -538,7 +709,7 @@ int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t*
     return wire_host(wire_vargen_locked, sig, 64, pk, 64, m, n, status, tally);
 }
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n == 0) return JJS_OK;
     if (!all_ok(in, affine_out) || !ok_out) return fail(JJS_ERR_ARG, "null or misaligned pointer");
@@ -548,7 +719,7 @@ int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out,
     return launch_decode(D, (hipStream_t)stream);
 }
 int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n == 0) return JJS_OK;
     if (!all_ok(affine, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
@@ -562,7 +733,7 @@ int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
 int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const void* S, const void* m,
                              const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* agg_pk,
                              void* sig_u, void* sig_R, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n_transcripts == 0) return JJS_OK;
     if (!offsets_host || offsets_host[0] != 0) return fail(JJS_ERR_ARG, "offsets must start at 0");
@@ -574,31 +745,31 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     const size_t n = offsets_host[n_transcripts];
     if (!all_ok(z, PK, R, S, m, agg_pk, sig_u, sig_R) || !share_status) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (n > g.msig_items || n_transcripts > g.msig_transcripts) {
-        if (g.msig) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g.msig)); g.msig = nullptr; }
+    if (n > g->msig_items || n_transcripts > g->msig_transcripts) {
+        if (g->msig) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->msig)); g->msig = nullptr; }
         size_t ci = n < 4096 ? 4096 : n, ct = n_transcripts < 1024 ? 1024 : n_transcripts;
-        HIP_TRY(hipMalloc(&g.msig, ci * 4 * (1 + 8 + 2 * EXT_WORDS) + ct * 4 * (16 + 1) + 64));
-        g.msig_items = ci; g.msig_transcripts = ct;
+        HIP_TRY(hipMalloc(&g->msig, ci * 4 * (1 + 8 + 2 * EXT_WORDS) + ct * 4 * (16 + 1) + 64));
+        g->msig_items = ci; g->msig_transcripts = ct;
     }
     msig_params P{};
     P.z = (const uint8_t*)z; P.PK = (const uint8_t*)PK; P.R = (const uint8_t*)R; P.S = (const uint8_t*)S; P.m = (const uint8_t*)m;
     P.n_transcripts = (uint32_t)n_transcripts; P.n_total = n;
     P.share_status = (uint8_t*)share_status; P.agg_pk = (uint8_t*)agg_pk; P.sig_u = (uint8_t*)sig_u; P.sig_R = (uint8_t*)sig_R;
-    uint32_t* w = (uint32_t*)g.msig;
-    P.tr_of = w; w += g.msig_items;
-    P.d_words = w; w += 8 * g.msig_items;
-    P.dpk = w; w += EXT_WORDS * g.msig_items;
-    P.e_pt = w; w += EXT_WORDS * g.msig_items;
-    P.a_words = w; w += 8 * g.msig_transcripts;
-    P.c_words = w; w += 8 * g.msig_transcripts;
+    uint32_t* w = (uint32_t*)g->msig;
+    P.tr_of = w; w += g->msig_items;
+    P.d_words = w; w += 8 * g->msig_items;
+    P.dpk = w; w += EXT_WORDS * g->msig_items;
+    P.e_pt = w; w += EXT_WORDS * g->msig_items;
+    P.a_words = w; w += 8 * g->msig_transcripts;
+    P.c_words = w; w += 8 * g->msig_transcripts;
     uint32_t* d_off = w;
     P.offsets = d_off;
-    P.tags = g.tags_long; P.comb_g = g.comb_g; P.lane_ws = g.workspace;
+    P.tags = g->tags_long; P.comb_g = g->comb_g; P.lane_ws = g->workspace;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     for (int pass = 0; pass < 6; ++pass) {
         const size_t count = (pass == 0 || pass == 2 || pass == 4) ? n_transcripts : n;
-        hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g.grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
+        hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g->grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
     }
     HIP_TRY(hipGetLastError());
     return end_shared(s);
@@ -616,7 +787,7 @@ static int launch_challenge(challenge_params P, void* stream) {
     return JJS_OK;
 }
 int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_t n, void* c_out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     verify_params V = params_single((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n, nullptr, out_ptrs{});
@@ -627,11 +798,11 @@ int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_
 }
 int jjs_challenge_double_dev(const void* R, const void* Rp, const void* PK, const void* PKp, const void* m, size_t n,
                              void* c_out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     verify_params V = params_double((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
-                                    (const uint8_t*)PKp, (const uint8_t*)m, n, g.tag, nullptr, nullptr, out_ptrs{});
+                                    (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, nullptr, nullptr, out_ptrs{});
     challenge_params P{};
     P.n_hash = V.n_hash; P.n = n; P.c_out = (uint8_t*)c_out;
     for (uint32_t i = 0; i < V.n_hash; ++i) P.hash_in[i] = V.hash_in[i];
@@ -639,7 +810,7 @@ int jjs_challenge_double_dev(const void* R, const void* Rp, const void* PK, cons
 }
 int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* c_out,
                              void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     verify_params V = params_vargen((const uint8_t*)m, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
@@ -654,15 +825,15 @@ int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, con
 static int launch_sign(sign_params P, void* stream) {
     if (P.n == 0) return JJS_OK;
     hipStream_t s = (hipStream_t)stream;
-    P.comb_g = g.comb_g; P.comb_gn = g.comb_gn; P.workspace = g.workspace;
+    P.comb_g = g->comb_g; P.comb_gn = g->comb_gn; P.workspace = g->workspace;
     if (int rc = begin_shared(s)) return rc;
-    hipLaunchKernelGGL(sign_kernel, dim3(grid_for(g.grid_sign, P.n)), dim3(BLOCK), 0, s, P);
+    hipLaunchKernelGGL(sign_kernel, dim3(grid_for(g->grid_sign, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
     return end_shared(s);
 }
 int jjs_sign_single_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out, void* PK_out,
                         void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sk, rnd, m, u_out, R_out, PK_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     sign_params P{};
@@ -672,7 +843,7 @@ int jjs_sign_single_dev(const void* sk, const void* rnd, const void* m, size_t n
 }
 int jjs_sign_double_dev(const void* sk, const void* rnd, const void* m, size_t n, void* u_out, void* R_out, void* Rp_out,
                         void* PK_out, void* PKp_out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sk, rnd, m, u_out, R_out, Rp_out, PK_out, PKp_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     sign_params P{};
@@ -683,7 +854,7 @@ int jjs_sign_double_dev(const void* sk, const void* rnd, const void* m, size_t n
 }
 int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd, const void* m, size_t n, void* u_out,
                         void* R_out, void* PK_out, void* Gen_out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n && !all_ok(sk, gen_scalar, rnd, m, u_out, R_out, PK_out, Gen_out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     sign_params P{};
@@ -695,7 +866,7 @@ int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd,
 
 // ---- debug primitives ------------------------------------------------------------------------------
 int jjs_debug_fq_mul_dev(const void* a, const void* b, size_t n, void* out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n == 0) return JJS_OK;
     if (!all_ok(a, b, out)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
@@ -706,7 +877,7 @@ int jjs_debug_fq_mul_dev(const void* a, const void* b, size_t n, void* out, void
     return JJS_OK;
 }
 int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (k < 1 || k > JJS_MAX_HASH_INPUTS) return fail(JJS_ERR_ARG, "k out of range");
     if (n == 0) return JJS_OK;
@@ -718,7 +889,7 @@ int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* 
     return JJS_OK;
 }
 int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n == 0) return JJS_OK;
     if (!points || !aligned16(points) || !out) return fail(JJS_ERR_ARG, "null or misaligned pointer");
@@ -729,16 +900,40 @@ int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* str
     return JJS_OK;
 }
 int jjs_debug_skip_phases(unsigned mask) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     g_skip_phases = mask & 7u;
+    return JJS_OK;
+}
+// Loads RCCL, forms a one-rank clique on the current device and sums a known 4 x u64 vector in place: checks
+// the library, the symbols and the call sequence of allreduce_tallies() on a box with a single GPU.
+int jjs_debug_rccl_selftest(void) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (int rc = load_rccl()) return rc;
+    ncclComm_t comm;
+    int ord = g->device;
+    RCCL_TRY(L.rccl.CommInitAll(&comm, 1, &ord));
+    const unsigned long long in[4] = {3, 1, 4, 0x100000001ull};
+    unsigned long long out[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(g->tally, in, sizeof(in), hipMemcpyHostToDevice, g->stream));
+    ncclResult_t r = L.rccl.GroupStart();
+    if (r == ncclSuccess) r = L.rccl.AllReduce(g->tally, g->tally, 4, ncclUint64, ncclSum, comm, g->stream);
+    ncclResult_t r2 = L.rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    hipError_t e = hipMemcpyAsync(out, g->tally, sizeof(out), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)L.rccl.CommDestroy(comm);
+    if (r != ncclSuccess) return fail(JJS_ERR_COLLECTIVE, "RCCL self-test: %s", L.rccl.GetErrorString(r));
+    if (e != hipSuccess) return fail(JJS_ERR_HIP, "RCCL self-test: %s", hipGetErrorString(e));
+    if (memcmp(in, out, sizeof(in)) != 0) return fail(JJS_ERR_COLLECTIVE, "RCCL self-test: wrong sum");
     return JJS_OK;
 }
 size_t jjs_debug_comb_table_bytes(void) { return COMB_TABLE_WORDS * sizeof(uint32_t); }
 int jjs_debug_comb_table(int which, void* host_out) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (!host_out) return fail(JJS_ERR_ARG, "null pointer");
-    HIP_TRY(hipMemcpy(host_out, which ? g.comb_gn : g.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_out, which ? g->comb_gn : g->comb_g, COMB_TABLE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return JJS_OK;
 }
 

@@ -1,0 +1,53 @@
+"""Child process of test_multidevice.py: one process driving several (logical) devices through the
+host-buffer entry points.  Run with JJS_DEBUG_VIRTUAL_DEVICES=1 on a one-GPU box, where the logical
+devices share the card (sharding, staging and status scatter are the real code; the tally sum is done on
+the host because two ranks on one card cannot form an RCCL clique)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.join(HERE, "..", "oracle"), os.path.join(HERE, "..")]
+
+from helpers import ARG_ORDER, edge_cases, make_batch, oracle_verify  # noqa: E402
+from test_gpu_parity import to_wire  # noqa: E402
+
+
+def main(devices: int) -> None:
+    import jubjub_schnorr_amd as jjs
+    eng = jjs.Engine(devices)
+    assert eng.device_count == devices, eng.device_count
+    for scheme in ("single", "double", "vargen"):
+        widths = [b.shape[1] for b in (make_batch(scheme, 1)[k] for k in ARG_ORDER[scheme])]
+        # n = 0, fewer items than devices (empty blocks), ragged and larger blocks
+        for n in (0, 1, devices - 1, devices + 1, 1000, 5003):
+            if n == 0:
+                arrays = [np.zeros((0, w), np.uint8) for w in widths]
+                want = np.zeros(0, np.uint8)
+            else:
+                b = make_batch(scheme, n, seed=900 + n, n_keys=8)
+                arrays = [b[k] for k in ARG_ORDER[scheme]]
+                want = oracle_verify(scheme, b)
+            st, tally = eng.verify(scheme, *arrays)
+            assert st.tolist() == want.tolist(), (scheme, n)
+            assert tally.tolist() == [int((want == k).sum()) for k in range(4)], (scheme, n, tally)
+        b = edge_cases(scheme)
+        want = oracle_verify(scheme, b)
+        st, tally = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])
+        assert st.tolist() == want.tolist() and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+        b = make_batch(scheme, 777, seed=31, n_keys=8)
+        want = oracle_verify(scheme, b)
+        st, tally = eng.verify_wire(scheme, *to_wire(scheme, b))
+        assert st.tolist() == want.tolist() and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    # the device-pointer calls still act on the current device
+    import torch
+    b = make_batch("single", 300, seed=77)
+    want = oracle_verify("single", b)
+    st, _ = eng.verify("single", *[torch.from_numpy(b[k]).cuda() for k in ARG_ORDER["single"]])
+    assert st.cpu().numpy().tolist() == want.tolist()
+    print("MULTIDEVICE OK", devices)
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]))

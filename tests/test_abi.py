@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.jjs_abi_version() == 1
+    assert lib.jjs_abi_version() == 2
 
 
 def test_python_binding_covers_the_header():
