@@ -38,11 +38,52 @@ __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
         const bool active = item < P.n;
         const uint64_t it = active ? item : P.n - 1;
         const uint32_t st = verify_item(P, it, ws, active);
-        if (active && P.status) P.status[item] = (uint8_t)st;
+        if (active && st < ST_PENDING_EQ_FAILED && P.status) P.status[item] = (uint8_t)st;
         if (P.tally) {
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 unsigned long long b = __ballot(active && st == k);
+                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
+            }
+        }
+        // items whose points still need their own subgroup tests: append to the queue of the resolve pass
+        // (one atomic per wave, entries of a wave contiguous)
+        const bool pend = active && st >= ST_PENDING_EQ_FAILED;
+        const unsigned long long pmask = __ballot(pend);
+        if (pmask) {
+            const uint32_t lane = threadIdx.x & 63;
+            unsigned long long slot = 0;
+            if (lane == 0) slot = atomicAdd(P.pending_count, (unsigned long long)__popcll(pmask));
+            slot = __shfl(slot, 0);
+            if (pend) P.pending[slot + __popcll(pmask & ((1ull << lane) - 1ull))] = (item << 1) | (st == ST_PENDING_EQ_HELD ? 1u : 0u);
+        }
+    }
+}
+
+// Second pass: the queued items, densely packed over the lanes, P.resolve_lanes adjacent lanes per item
+// (one point each; see verify_item / resolve_point).
+__global__ __launch_bounds__(BLOCK) void resolve_kernel(verify_params P) {
+    const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t count = *P.pending_count;
+    const uint32_t L = P.resolve_lanes;
+    for (uint64_t base = 0; base < count * L; base += total) {
+        const uint64_t slot = base + gtid;
+        const uint64_t idx = slot / L;
+        const uint32_t j = (uint32_t)(slot % L);
+        const bool active = idx < count;
+        if (!__ballot(active)) break;                       // a wave past the end of the queue has nothing to do
+        const uint64_t e = P.pending[active ? idx : count - 1];
+        const uint64_t item = e >> 1;
+        bool tf = resolve_point(P, item, j);
+        for (uint32_t d = 1; d < L; d <<= 1) tf = (__shfl_xor((int)tf, (int)d) != 0) && tf;
+        const uint32_t st = resolve_status(tf, (e & 1u) != 0);
+        const bool writer = active && j == 0;
+        if (writer && P.status) P.status[item] = (uint8_t)st;
+        if (P.tally) {
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                unsigned long long b = __ballot(writer && st == k);
                 if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
             }
         }
@@ -162,7 +203,7 @@ struct device_state {
     uint8_t* tag = nullptr;
     uint32_t* workspace = nullptr;
     unsigned long long* tally = nullptr;
-    int grid_verify = 0, grid_sign = 0;
+    int grid_verify = 0, grid_sign = 0, grid_resolve = 0;
     size_t ws_lanes = 0;
     hipEvent_t last_use = nullptr;  // end of the last launch that used the shared workspaces
     uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
@@ -173,6 +214,8 @@ struct device_state {
     int grid_msig = 0;
     uint8_t* wire = nullptr;       // decoded points (4 x n x 64) + flags (n) for the *_wire entry points
     size_t wire_items = 0;
+    uint64_t* pending = nullptr;   // queue of the resolve pass: [0] = count, then one entry per queued item
+    size_t pending_items = 0;
 };
 
 // RCCL is needed only when one process drives several devices, so it is loaded on demand.
@@ -239,11 +282,31 @@ int end_shared(hipStream_t s) {
     return JJS_OK;
 }
 
+int ensure_pending(size_t n) {
+    if (n <= g->pending_items) return JJS_OK;
+    if (g->pending) {
+        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still use the old queue
+        HIP_TRY(hipFree(g->pending));
+        g->pending = nullptr; g->pending_items = 0;
+    }
+    size_t cap = n < 65536 ? 65536 : n;
+    HIP_TRY(hipMalloc(&g->pending, (cap + 2) * sizeof(uint64_t)));
+    g->pending_items = cap;
+    return JJS_OK;
+}
+
+// Two launches per batch: the verify pass, then the resolve pass over the items it queued (normally the
+// invalid ones only; the grid is sized for the batch, lanes without a queue entry leave at once).
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
     P.skip_phases = g_skip_phases;
+    if (int rc = ensure_pending(P.n)) return rc;
+    P.pending_count = reinterpret_cast<unsigned long long*>(g->pending);
+    P.pending = g->pending + 2;
     if (int rc = begin_shared(s)) return rc;
+    HIP_TRY(hipMemsetAsync(g->pending, 0, sizeof(uint64_t), s));
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
+    hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(g->grid_resolve, P.n * P.resolve_lanes)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
     return end_shared(s);
 }
@@ -290,7 +353,9 @@ int init_device(device_state& d, int ordinal) {
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d.last_use, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(d.last_use, d.stream));
-    int per_cu_v = 0, per_cu_s = 0, per_cu_m = 0;
+    int per_cu_v = 0, per_cu_s = 0, per_cu_m = 0, per_cu_r = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, resolve_kernel, BLOCK, 0));
+    d.grid_resolve = prop.multiProcessorCount * (per_cu_r < 1 ? 1 : per_cu_r);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, sign_kernel, BLOCK, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_m, msig_kernel, BLOCK, 0));
@@ -327,7 +392,8 @@ void free_device(device_state& d) {
     if (d.device < 0) return;
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
-    void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash};
+    void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash,
+                    d.pending};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (d.last_use) (void)hipEventDestroy(d.last_use);

@@ -26,6 +26,10 @@
 namespace jjs {
 
 enum : uint32_t { ST_OK = 0, ST_INVALID_POINT = 1, ST_INVALID_SIGNATURE = 2, ST_MALFORMED = 3 };
+// Internal results of the first pass (never written to the caller's status array): the item's points are
+// on the curve and not the identity, but the first pass did not prove all of them torsion-free; the
+// resolve pass tests each of them and turns the code into 0, 1 or 2 (see verify_item / resolve_item).
+enum : uint32_t { ST_PENDING_EQ_FAILED = 4, ST_PENDING_EQ_HELD = 5 };
 
 struct fe_src {            // where transcript element / coordinate e of item i lives: base + i*stride + off
     const uint8_t* base;
@@ -51,6 +55,10 @@ struct verify_params {
     uint8_t* c_out;                  // n x 32 bytes challenge (debug export), or nullptr
     const uint8_t* pre_malformed;    // n bytes from the wire decoder (non-zero: an encoding was rejected), or nullptr
     uint32_t* workspace;             // WS_WORDS_PER_LANE words per resident lane
+    uint32_t own_test_mask;          // bit k: points[k] gets its own subgroup test in the first pass
+    uint32_t resolve_lanes;          // lanes per queued item in the resolve pass: 1, 2 or 4 >= points left to test
+    uint64_t* pending;               // queue of items left to the resolve pass: item << 1 | equations held
+    unsigned long long* pending_count;
 };
 
 constexpr int TABLE_ENTRIES = 9;                 // {0..8} * P
@@ -400,15 +408,18 @@ JJS_HD bool is_torsion_free_by_order(const fe_n& u, const fe_n& v) {
 // denominators modulo 8th powers (derivation and constants: tools/gen_constants.py).  g vanishes on
 // the small-order points it cannot evaluate (including the identity), which yields "false"; the
 // caller rejects the identity separately, as the reference does.
-JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
-    auto opv = fq_add(fq_one(), v);                       // 1 + v          <2,3>
-    auto omv = fq_sub(fq_one(), v);                       // 1 - v          <3,4>
-    fe_n w = fq_mul(omv, u);                              // W = (1-v) u
-    fe_n x = fq_mul(opv, u);                              // X = (1+v) u
+// Projective form: for P = (X : Y : Z) the affine expression has denominator Z^48 = (Z^6)^8, an 8th power,
+// so the numerators alone give the same residue class.
+JJS_HD bool pairing_is_trivial(const fe_n& px, const fe_n& py, const fe_n& pz) {
+    auto opv = fq_add(pz, py);                            // Z + Y
+    auto omv = fq_sub(pz, py);                            // Z - Y
+    fe_n w = fq_mul(omv, px);                             // W = (Z-Y) X
+    fe_n x = fq_mul(opv, px);                             // X' = (Z+Y) X
+    fe_n oz = fq_mul(opv, pz);                            // (Z+Y) Z
     fe_n xw[2] = {x, w};
-    auto l1 = fq_norm(fq_add(opv, fq_dot_const<2, 2>(JJS_PAIR_L1, xw)));                       // <1,5>
-    auto l2 = fq_norm(fq_add(opv, fq_mul(x, fe_from_const<1, 1>(JJS_PAIR_NEG_L2))));          // <1,5>
-    auto vv = fq_norm(fq_sub(x, w));                                                           // <1,5>
+    auto l1 = fq_norm(fq_add(oz, fq_dot_const<2, 2>(JJS_PAIR_L1, xw)));
+    auto l2 = fq_norm(fq_add(oz, fq_mul(x, fe_from_const<1, 1>(JJS_PAIR_NEG_L2))));
+    auto vv = fq_norm(fq_sub(x, w));
     fe_n a = fq_mul(fq_sqr(l1), l2);
     a = fq_sqr(fq_mul(a, fq_sqr(vv)));                    // L1^4 L2^2 V^4
     fe_n y = fq_mul(fq_mul(x, w), fe_from_const<1, 1>(JJS_PAIR_B));
@@ -418,13 +429,11 @@ JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) {
     fe_n e = fq_pow_schedule(g, JJS_PAIR_SW, JJS_PAIR_SW_STEPS, JJS_PAIR_SW_TRAILING);
     return fq_eq(e, fq_one());
 }
+JJS_HD bool is_torsion_free(const fe_n& u, const fe_n& v) { return pairing_is_trivial(u, v, fe_n_one()); }
 
-// is_torsion_free && is_on_curve && !is_identity  (src/keys/public.rs:159-164)
-JJS_HD bool point_is_valid(const fe_n& u, const fe_n& v) {
-    bool on = affine_on_curve(u, v);
-    bool id = affine_is_identity(u, v);
-    bool tf = is_torsion_free(u, v);
-    return tf && on && !id;
+// is_on_curve && !is_identity: the cheap part of `is_valid` (src/keys/public.rs:159-164)
+JJS_HD bool point_on_curve_not_identity(const fe_n& u, const fe_n& v) {
+    return affine_on_curve(u, v) && !affine_is_identity(u, v);
 }
 
 JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
@@ -535,7 +544,29 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
     return ext_eq_affine(acc, ru, rv);
 }
 
-// one signature; ws = this lane's WS_WORDS_PER_LANE workspace words
+// One pairing test per fixed-generator equation instead of one per point.  Write PK = P + S and R = Q + T with
+// P, Q of order r and S, T in the 2-Sylow subgroup (cyclic of order 8, so S and T are residues mod 8).  The
+// pairing residue is a homomorphism that is trivial exactly on the prime-order subgroup, hence the test on
+// W = R + k*PK says T + k*S = 0 (mod 8).  The half-size equation (b*u)G + a*PK - b*R == O says, on the torsion
+// part, a*S - b*T = 0 (mod 8).  With k = 0 when a is odd and k = 1 when a is even and b odd, the determinant
+// of the two relations is odd, so together they force S = T = 0: both points are torsion-free and the equation
+// is the reference's.  If either test fails nothing is concluded and the item goes to the resolve pass.
+// (The addition law is complete on JubJub, so W and the equation are computed exactly for any curve points.)
+JJS_HD bool combined_subgroup_test(const eq_desc& E, uint64_t item, const half_scalars& h) {
+    const bool a_odd = (h.a.w[0] & 1u) != 0, b_odd = (h.b.w[0] & 1u) != 0;
+    fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
+    fe_n pu = load_fq(E.pk, item), pv = load_fq(E.pk, item, 32);
+    niels_pt n = niels_select(!a_odd, to_niels(ext_from_affine(pu, pv)), niels_identity());
+    ext_pt w = ext_add_affine_niels(ext_from_affine(ru, rv), n.ypx, n.ymx, n.t2d, false);
+    return (a_odd || b_odd) && pairing_is_trivial(w.x, w.y, w.z);
+}
+
+// First pass over one signature; ws = this lane's WS_WORDS_PER_LANE workspace words.  Returns the final
+// status, or ST_PENDING_* when the points' subgroup membership is still open:
+//  * fixed generator (single, double): see combined_subgroup_test -- status Ok needs the equation and the
+//    combined test to hold; anything else is pending;
+//  * per-item generator: PK and Gen get their own tests (own_test_mask); if the equation holds, R equals
+//    u*Gen + c*PK and is torsion-free with them; if it fails, R's test is pending.
 JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws, bool write_c = true) {
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
@@ -544,10 +575,12 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
     for (uint32_t e = 0; e < P.n_hash; ++e) malformed = malformed || !words_lt(load_words(P.hash_in[e], item), JJS_Q_WORDS);
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
+    const bool check_points = !(P.skip_phases & 1u);
     bool valid = true;
-    for (uint32_t k = 0; k < ((P.skip_phases & 1u) ? 0u : P.n_points); ++k) {
+    for (uint32_t k = 0; k < (check_points ? P.n_points : 0u); ++k) {
         fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
-        valid = point_is_valid(pu, pv) && valid;
+        valid = point_on_curve_not_identity(pu, pv) && valid;
+        if ((P.own_test_mask >> k) & 1u) valid = is_torsion_free(pu, pv) && valid;
     }
 
     // 3. challenge
@@ -558,14 +591,49 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
     }
     if (P.c_out && write_c) store_words(P.c_out, item, c);
 
-    // 4. equations
-    bool eq_ok = true;
+    // 4. equations (and the combined subgroup tests that ride on them)
+    bool eq_ok = true, proven = true;
     const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
     half_scalars h{};
     if (n_eq && P.eq[0].comb) h = half_size_scalars(c);     // shared by both equations of the double scheme
-    for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, c, h) && eq_ok;
+    for (uint32_t k = 0; k < n_eq; ++k) {
+        if (check_points && P.eq[k].comb) proven = combined_subgroup_test(P.eq[k], item, h) && proven;
+        eq_ok = check_equation(P.eq[k], item, ws, u, c, h) && eq_ok;
+    }
+    if (malformed) return ST_MALFORMED;
+    if (!valid) return ST_INVALID_POINT;
+    if (!check_points) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;
+    if (eq_ok && proven) return ST_OK;
+    return eq_ok ? ST_PENDING_EQ_HELD : ST_PENDING_EQ_FAILED;
+}
 
-    return malformed ? ST_MALFORMED : (!valid ? ST_INVALID_POINT : (!eq_ok ? ST_INVALID_SIGNATURE : ST_OK));
+// Resolve pass for an item the first pass left pending: every point that has not had its own subgroup
+// test gets it now (`is_torsion_free`, src/keys/public.rs:159-164), then the reference's precedence applies.
+// resolve_point is one such test (the j-th point without its own first-pass test; true beyond the last one),
+// so that the device can give each point of an item to a different lane.
+JJS_HD bool resolve_point(const verify_params& P, uint64_t item, uint32_t j) {
+    // pick the source first, test once: lanes of a wave hold different j and must not take turns
+    fe_src src = P.points[0];
+    bool found = false;
+    uint32_t seen = 0;
+    for (uint32_t k = 0; k < P.n_points; ++k) {
+        if ((P.own_test_mask >> k) & 1u) continue;
+        const bool hit = (seen++ == j);
+        src.base = hit ? P.points[k].base : src.base;
+        src.stride = hit ? P.points[k].stride : src.stride;
+        src.off = hit ? P.points[k].off : src.off;
+        found = found || hit;
+    }
+    fe_n pu = load_fq(src, item), pv = load_fq(src, item, 32);
+    return is_torsion_free(pu, pv) || !found;
+}
+JJS_HD uint32_t resolve_status(bool all_torsion_free, bool eq_held) {
+    return !all_torsion_free ? ST_INVALID_POINT : (eq_held ? ST_OK : ST_INVALID_SIGNATURE);
+}
+JJS_HD uint32_t resolve_item(const verify_params& P, uint64_t item, bool eq_held) {
+    bool valid = true;
+    for (uint32_t j = 0; j < P.n_points; ++j) valid = resolve_point(P, item, j) && valid;
+    return resolve_status(valid, eq_held);
 }
 
 // ---- fixed-base comb table: entry (i, b) = b * 256^i * Base as an affine cached addend ------------

@@ -205,3 +205,50 @@ def make_multisig_batch(n_transcripts: int, seed: int = 5, max_n: int = 5, corru
         z += zs; PK += pks; R += Rs; S += Ss; m.append(msg); offs.append(offs[-1] + n); want += st
         info.append((agg, sum(zs) % o.R_ORDER, rsa))
     return (fe_arr(z), pt_arr(PK), pt_arr(R), pt_arr(S), fe_arr(m), np.array(offs, np.uint32), np.array(want, np.uint8), info)
+
+
+def torsion_grid(scheme: str, seed: int = 77, extra: int = 0, reps: int = 6):
+    """Signatures whose prime-order parts satisfy (or, for every third item, miss) the verification
+    equation while every point carries a chosen component of the order-8 subgroup: the cases that separate a
+    per-point subgroup test from any test that looks at combinations of the points.  single: all 64
+    (S, T) pairs, `reps` times (the scalars' parities matter); double / vargen: all pairs on (PK, R) with
+    the other points clean, then `extra` random
+    assignments over all points.  Returns a batch dict like make_batch."""
+    rng = np.random.default_rng(seed)
+    t8 = torsion_generator()
+    tors = [o.mul(t8, i) if i else o.IDENTITY for i in range(8)]
+    names = {"single": ["PK", "R"], "double": ["PK", "R", "PKp", "Rp"], "vargen": ["PK", "R", "Gen"]}[scheme]
+    combos = [dict(zip(names, [i, j] + [0] * (len(names) - 2))) for i in range(8) for j in range(8)] * reps
+    combos += [dict.fromkeys(names, 0)] * 6          # clean points: statuses 0 and 2
+    for _ in range(extra):
+        combos.append({k: int(rng.integers(0, 8)) for k in names})
+    rows = {k: [] for k in ARG_ORDER[scheme]}
+    for idx, tc in enumerate(combos):
+        sk = int.from_bytes(rng.bytes(40), "little") % (o.R_ORDER - 1) + 1
+        k = int.from_bytes(rng.bytes(40), "little") % (o.R_ORDER - 1) + 1
+        m = int.from_bytes(rng.bytes(40), "little") % o.Q
+        wrong = int(rng.integers(0, 4) == 0)          # prime-order part of the equation off by one base point
+        if scheme == "vargen":
+            gen = o.add(o.mul(o.G, int.from_bytes(rng.bytes(40), "little") % (o.R_ORDER - 1) + 1), tors[tc["Gen"]])
+            base = o.mul(gen, 8 * pow(8, -1, o.R_ORDER) % o.R_ORDER)      # prime-order part of Gen
+        else:
+            gen, base = None, o.G
+        PK = o.add(o.mul(base, sk), tors[tc["PK"]])
+        R = o.add(o.mul(base, k + wrong), tors[tc["R"]])
+        if scheme == "single":
+            c = o.challenge_single(R, PK, m)
+        elif scheme == "double":
+            PKp = o.add(o.mul(o.G_NUMS, sk), tors[tc["PKp"]])
+            Rp = o.add(o.mul(o.G_NUMS, k + wrong), tors[tc["Rp"]])
+            c = o.challenge_double(R, Rp, PK, PKp, m)
+        else:
+            c = o.challenge_vargen(R, PK, gen, m)
+        u = (k - c * sk) % o.R_ORDER
+        vals = {"u": fe_bytes(u), "R": pt_bytes(R), "PK": pt_bytes(PK), "m": fe_bytes(m)}
+        if scheme == "double":
+            vals.update(Rp=pt_bytes(Rp), PKp=pt_bytes(PKp))
+        if scheme == "vargen":
+            vals.update(Gen=pt_bytes(gen))
+        for key in rows:
+            rows[key].append(vals[key])
+    return {key: np.stack(v) for key, v in rows.items()}

@@ -31,6 +31,7 @@ static void run(verify_params P) {
     uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
     for (uint64_t i = 0; i < P.n; ++i) {
         uint32_t st = verify_item(P, i, w);
+        if (st >= ST_PENDING_EQ_FAILED) st = resolve_item(P, i, st == ST_PENDING_EQ_HELD);
         if (P.status) P.status[i] = (uint8_t)st;
         if (P.tally) P.tally[st]++;
     }

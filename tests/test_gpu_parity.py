@@ -8,7 +8,8 @@ import pytest
 
 import jjs_oracle as o
 import jjs_oracle_c as oc
-from helpers import (ARG_ORDER, edge_cases, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator)
+from helpers import (ARG_ORDER, edge_cases, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
+                     torsion_grid)
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -108,6 +109,19 @@ def test_verify_host_buffers_and_edge_cases(eng, scheme):
     assert st.tolist() == want.tolist()
     assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
     assert set(want.tolist()) == {0, 1, 2, 3}
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_every_torsion_component_is_caught(eng, scheme):
+    """Small-order components on every point, with the prime-order parts satisfying the equation or not: the
+    two-pass subgroup logic (combined pairing test, resolve pass) must give the reference's per-point statuses."""
+    b = torsion_grid(scheme, extra=0 if scheme == "single" else 300)
+    want = oracle_verify(scheme, b)
+    st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
+    assert host(st).tolist() == want.tolist()
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    _, tally_only = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]], want_status=False)
+    assert host(tally_only).tolist() == host(tally).tolist()
 
 
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])

@@ -6,7 +6,8 @@ import pytest
 import hostlib as hl
 import jjs_oracle as o
 import jjs_oracle_c as oc
-from helpers import edge_cases, fe_arr, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator
+from helpers import (edge_cases, fe_arr, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
+                     torsion_grid)
 
 
 def special_fq(rng, n):
@@ -81,6 +82,18 @@ def test_verify_matches_oracle_on_edge_cases(scheme):
     want = oracle_verify(scheme, b)
     st, _ = hl.verify(scheme, b)
     assert st.tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_every_torsion_component_is_caught(scheme):
+    """The first pass tests combinations of points (one pairing test per equation); the statuses must still be
+    the per-point ones of the reference for every choice of small-order components."""
+    b = torsion_grid(scheme, extra=0 if scheme == "single" else 150)
+    want = oracle_verify(scheme, b)
+    st, tally = hl.verify(scheme, b)
+    assert st.tolist() == want.tolist()
+    assert set(want.tolist()) == {0, 1, 2}
+    assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
 
 
 def test_half_size_scalars():
