@@ -1,0 +1,106 @@
+"""Assemble profiles/<tag>_pmc_summary.json and profiles/pmc_latest.json from rocprofv3 CSV output.
+
+    python jubjub_schnorr_amd/tools/pmc_summary.py <tag> <variant text> <trace_dir> <pmc_dir> [<pmc_dir> ...]
+
+<trace_dir>: output of  rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
+<pmc_dir>s : outputs of rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py ...   (one pass per
+             counter group, as MI355X_MICROARCH.md prescribes)
+One batch = one verify_kernel launch followed by one resolve_kernel launch; counters are summed over the two
+and averaged over the batches of the run.  HBM bytes = FETCH_SIZE (KB) x 2 (gfx950 correction for 16 B/lane
+loads) + WRITE_SIZE (KB).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = ("verify_kernel", "resolve_kernel")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def kernel_of(name: str):
+    for k in KERNELS:
+        if k + "(" in name:
+            return k
+    return None
+
+
+def read_counters(d):
+    out = {}
+    meta = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = kernel_of(row["Kernel_Name"])
+            if not k:
+                continue
+            out.setdefault(row["Counter_Name"], {}).setdefault(k, []).append(float(row["Counter_Value"]))
+            if k == "verify_kernel":
+                meta = {"grid_size": int(row["Grid_Size"]), "lds_block_size": int(row["LDS_Block_Size"]),
+                        "scratch_size": int(row["Scratch_Size"]), "vgpr_count": int(row["VGPR_Count"]),
+                        "sgpr_count": int(row["SGPR_Count"])}
+    return out, meta
+
+
+def read_stats(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = kernel_of(row["Name"])
+            if k:
+                out[k] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
+                          "min_ms": float(row["MinNs"]) / 1e6, "max_ms": float(row["MaxNs"]) / 1e6}
+    return out
+
+
+def main():
+    tag, variant, trace_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
+    stats = read_stats(trace_dir)
+    counters, meta = {}, {}
+    for d in pmc_dirs:
+        c, m = read_counters(d)
+        counters.update(c)
+        meta = m or meta
+    summary = {"round": 1, "variant": variant,
+               "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+                          "--no-cpu-baseline (one pass per counter group); kernel times from a separate "
+                          "rocprofv3 --kernel-trace --stats run",
+               "kernels": list(KERNELS), "scheme": "single", "items": 1 << 20, "counters": {}}
+    per_batch = {}
+    for name, by_kernel in sorted(counters.items()):
+        entry = {}
+        total = 0.0
+        for k, vals in by_kernel.items():
+            entry[k] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
+            total += sum(vals) / len(vals)
+        entry["per_batch"] = total
+        per_batch[name] = total
+        summary["counters"][name] = entry
+    summary.update(meta)
+    summary["kernel_ms_rocprof"] = stats
+    batch_ms = sum(v["avg_ms"] for v in stats.values())
+    summary["batch_ms_rocprof"] = batch_ms
+    if "FETCH_SIZE" in per_batch and "WRITE_SIZE" in per_batch:
+        summary["hbm_bytes_per_launch"] = (2.0 * per_batch["FETCH_SIZE"] + per_batch["WRITE_SIZE"]) * 1024.0
+        summary["hbm_bytes_note"] = ("FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md HBM section (16 B/lane loads; "
+                                     "gather-like access, so an upper estimate), WRITE_SIZE (KB) as is; verify + resolve")
+    summary["algorithmic_bytes_per_launch"] = 196 * (1 << 20)
+    if "SQ_INSTS_VALU" in per_batch:
+        valu = per_batch["SQ_INSTS_VALU"]
+        summary["valu_wave_instr_per_launch"] = valu
+        summary["valu_wave_instr_per_64_verifies"] = valu / ((1 << 20) / 64)
+        if "GRBM_GUI_ACTIVE" in per_batch and batch_ms:
+            cycles = per_batch["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+            summary["effective_clock_ghz"] = cycles / (batch_ms * 1e-3) / 1e9
+            summary["cycles_per_valu_instr_per_simd"] = cycles * 1024 / valu
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+    json.dump(summary, open(out, "w"), indent=1)
+    latest = {"scheme": "single", "items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
+              "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
+              "source": f"profiles/{tag}_pmc_summary.json"}
+    json.dump(latest, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    print(json.dumps({k: summary[k] for k in summary if k not in ("counters",)}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
