@@ -967,7 +967,7 @@ int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* str
 }
 int jjs_debug_skip_phases(unsigned mask) {
     std::lock_guard<std::mutex> lock(L.mu);
-    g_skip_phases = mask & 7u;
+    g_skip_phases = mask & 15u;
     return JJS_OK;
 }
 // Loads RCCL, forms a one-rank clique on the current device and sums a known 4 x u64 vector in place: checks

@@ -44,7 +44,7 @@ struct eq_desc {           // u*Gen + c*PK == R
 };
 struct verify_params {
     uint32_t n_hash, n_points, n_eq;
-    uint32_t skip_phases;            // profiling only (bit0 validity, bit1 challenge, bit2 equations); 0 in production
+    uint32_t skip_phases;            // profiling only (bit0 validity, bit1 challenge, bit2 equations, bit3 Euclid); 0 in production
     fe_src hash_in[10];
     fe_src points[4];
     eq_desc eq[2];
@@ -595,7 +595,14 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
     bool eq_ok = true, proven = true;
     const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
     half_scalars h{};
-    if (n_eq && P.eq[0].comb) h = half_size_scalars(c);     // shared by both equations of the double scheme
+    if (n_eq && P.eq[0].comb) {                             // shared by both equations of the double scheme
+        if (P.skip_phases & 8u) {                           // profiling only: stand-in scalars, no Euclid
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h.a.w[i] = c.w[i] >> 2; h.b.w[i] = c.w[4 + i] >> 2; }
+        } else {
+            h = half_size_scalars(c);
+        }
+    }
     for (uint32_t k = 0; k < n_eq; ++k) {
         if (check_points && P.eq[k].comb) proven = combined_subgroup_test(P.eq[k], item, h) && proven;
         eq_ok = check_equation(P.eq[k], item, ws, u, c, h) && eq_ok;

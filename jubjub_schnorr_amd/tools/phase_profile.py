@@ -32,13 +32,18 @@ def main():
             best = min(best, e0.elapsed_time(e1))
         return best
 
+    # bit0: point checks (cheap checks, pairing tests, hence no resolve pass); bit1: challenge; bit2: equations;
+    # bit3: Euclid.  Differences are taken between runs that agree on everything else, and never against a run
+    # whose equations all fail (that would send every item through the resolve pass).
     full = timed(0)
     out = {"scheme": scheme, "items": 1 << log2n, "ms_full": full,
-           "ms_without_validity": timed(1), "ms_without_challenge": timed(2), "ms_without_equations": timed(4),
-           "ms_only_loads_and_tally": timed(7)}
+           "ms_without_validity": timed(1), "ms_without_equations": timed(4),
+           "ms_without_equations_and_challenge": timed(6), "ms_without_validity_and_equations": timed(5),
+           "ms_without_validity_and_euclid": timed(9), "ms_only_loads_and_tally": timed(7)}
     out["ms_validity"] = full - out["ms_without_validity"]
-    out["ms_challenge"] = full - out["ms_without_challenge"]
-    out["ms_equations"] = full - out["ms_without_equations"]
+    out["ms_challenge"] = out["ms_without_equations"] - out["ms_without_equations_and_challenge"]
+    out["ms_equations"] = out["ms_without_validity"] - out["ms_without_validity_and_equations"]
+    out["ms_euclid"] = out["ms_without_validity"] - out["ms_without_validity_and_euclid"]
     _ffi.lib().jjs_debug_skip_phases(0)
     print(json.dumps(out))
 
