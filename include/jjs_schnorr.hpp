@@ -89,6 +89,46 @@ inline std::vector<VerifyResult> results(const std::vector<uint8_t>& status) {
 }
 }  // namespace detail
 
+// The reference's serde form (src/serde_support.rs:21-46 and the same pattern for every type): a JSON
+// string holding the base58 (Bitcoin alphabet) text of `to_bytes()`.  Decoding fails, like the reference's
+// deserialiser, on a character outside the alphabet or a decoded length other than N.
+namespace serde {
+inline const char* alphabet() { return "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"; }
+template <size_t N>
+inline std::array<uint8_t, N> from_base58(const std::string& text) {
+    std::vector<uint8_t> num;                       // big-endian base-256 digits, most significant first
+    size_t zeros = 0;
+    while (zeros < text.size() && text[zeros] == '1') ++zeros;
+    for (char ch : text) {
+        const char* pos = std::strchr(alphabet(), ch);
+        if (!pos || ch == 0) throw std::invalid_argument("invalid base58 character");
+        unsigned carry = (unsigned)(pos - alphabet());
+        for (size_t i = num.size(); i-- > 0;) { carry += 58u * num[i]; num[i] = (uint8_t)carry; carry >>= 8; }
+        while (carry) { num.insert(num.begin(), (uint8_t)carry); carry >>= 8; }
+    }
+    size_t lead = 0;
+    while (lead < num.size() && num[lead] == 0) ++lead;
+    if (zeros + (num.size() - lead) != N) throw std::invalid_argument("invalid length");
+    std::array<uint8_t, N> out{};
+    std::copy(num.begin() + lead, num.end(), out.begin() + zeros);
+    return out;
+}
+template <size_t N>
+inline std::string to_base58(const std::array<uint8_t, N>& bytes) {
+    std::vector<uint8_t> digits;                    // base-58 digits, least significant first
+    size_t zeros = 0;
+    while (zeros < N && bytes[zeros] == 0) ++zeros;
+    for (uint8_t b : bytes) {
+        unsigned carry = b;
+        for (auto& d : digits) { carry += 256u * d; d = (uint8_t)(carry % 58u); carry /= 58u; }
+        while (carry) { digits.push_back((uint8_t)(carry % 58u)); carry /= 58u; }
+    }
+    std::string out(zeros, '1');
+    for (size_t i = digits.size(); i-- > 0;) out.push_back(alphabet()[digits[i]]);
+    return out;
+}
+}  // namespace serde
+
 // `Signature { u, R }` (reference src/signatures.rs:62-65)
 struct Signature {
     JubJubScalar u;

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         std::istringstream ss(line);
         std::string scheme, name; int want;
         ss >> scheme;
-        if (scheme == "wire") continue;
+        if (scheme == "wire" || scheme == "serde") continue;
         ss >> name >> want;
         std::vector<std::string> f; std::string tok;
         while (ss >> tok) f.push_back(tok);
@@ -78,6 +78,27 @@ int main(int argc, char** argv) {
         auto wres = jjs::PublicKey::verify_batch_bytes(wire);
         for (size_t i = 0; i < wres.size(); ++i) failures += expect(wres[i], wire_want[i], "wire[" + std::to_string(i) + "]");
         n += (int)wire.size();
+    }
+    // serde strings (line "serde single <name> <status> sig58 pk58 m-hex"): base58 -> bytes -> wire entry point,
+    // and the text round-trips
+    {
+        std::ifstream in3(argv[1]);
+        while (std::getline(in3, line)) {
+            std::istringstream ss(line);
+            std::string tag, scheme, name; int want;
+            ss >> tag;
+            if (tag != "serde") continue;
+            ss >> scheme >> name >> want;
+            std::string a, b, c; ss >> a >> b >> c;
+            auto sig = jjs::serde::from_base58<64>(a);
+            auto pk = jjs::serde::from_base58<32>(b);
+            if (jjs::serde::to_base58(sig) != a || jjs::serde::to_base58(pk) != b) { std::printf("FAIL base58 round trip %s\n", name.c_str()); ++failures; }
+            failures += expect(jjs::PublicKey::verify_batch_bytes({{pk, sig, unhex<32>(c)}})[0], want, "serde " + name);
+            ++n;
+        }
+        bool threw = false;
+        try { jjs::serde::from_base58<32>("0OIl"); } catch (const std::invalid_argument&) { threw = true; }
+        if (!threw) { std::puts("FAIL base58 accepts characters outside the alphabet"); ++failures; }
     }
     if (jjs::PublicKey::verify_batch({}).size() != 0) { std::puts("FAIL empty batch"); ++failures; }
     std::printf("%d vectors, %d failures\n", n, failures);

@@ -45,6 +45,7 @@ def test_cpp_mirror_reference_scenarios(tmp_path):
     lines.append(f"wire single multisig_kat 0 {k['signature']} {k['aggregate_public_key']} {o.le32(k['message']).hex()}")
     lines.append(f"wire single bad_pk_encoding 3 {sig} {o.le32(o.Q).hex()} {m}")
     lines.append(f"wire single wrong_message 2 {sig} {pk} {o.le32(5).hex()}")
+    lines.append(f"serde single reference_strings 0 {v['serde_signature']} {v['serde_public_key']} {m}")
     path = tmp_path / "vectors.txt"
     path.write_text("\n".join(lines) + "\n")
     exe = build(tmp_path)
