@@ -216,6 +216,10 @@ struct device_state {
     size_t wire_items = 0;
     uint64_t* pending = nullptr;   // queue of the resolve pass: [0] = count, then one entry per queued item
     size_t pending_items = 0;
+    hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
+    uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
+    size_t stage_bytes = 0;
+    hipEvent_t chunk_up[33] = {}, chunk_done[33] = {};
 };
 
 // RCCL is needed only when one process drives several devices, so it is loaded on demand.
@@ -327,23 +331,12 @@ bool all_ok(Ptrs... p) {
     return ((p != nullptr && aligned16(p)) && ...);
 }
 
+extern bool g_keep_tally;
 int verify_dev_common(verify_params P, void* status, void* tally, hipStream_t s) {
     if (status && !aligned16(status)) return fail(JJS_ERR_ARG, "status must be 16-byte aligned");
-    if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
+    if (tally && !g_keep_tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
     return launch_verify(P, s);
 }
-
-// host-buffer wrapper: stage inputs, run, copy back
-struct staged {
-    void* d = nullptr;
-    ~staged() { if (d) (void)hipFree(d); }
-    int up(const void* h, size_t bytes, hipStream_t s) {
-        HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
-        if (bytes) HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
-        return JJS_OK;
-    }
-    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&d, bytes ? bytes : 16)); return JJS_OK; }
-};
 
 int init_device(device_state& d, int ordinal) {
     d.device = ordinal;
@@ -351,6 +344,11 @@ int init_device(device_state& d, int ordinal) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 33; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&d.chunk_up[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d.chunk_done[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&d.last_use, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(d.last_use, d.stream));
     int per_cu_v = 0, per_cu_s = 0, per_cu_m = 0, per_cu_r = 0;
@@ -393,10 +391,15 @@ void free_device(device_state& d) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
     void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash,
-                    d.pending};
+                    d.pending, d.stage};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (d.last_use) (void)hipEventDestroy(d.last_use);
+    for (int i = 0; i < 33; ++i) {
+        if (d.chunk_up[i]) (void)hipEventDestroy(d.chunk_up[i]);
+        if (d.chunk_done[i]) (void)hipEventDestroy(d.chunk_done[i]);
+    }
+    if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = device_state{};
 }
@@ -470,11 +473,29 @@ struct device_restore {   // puts the calling thread back on the device it came 
     ~device_restore() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-// Host-buffer calls: the batch is cut into one contiguous block of ceil(n / devices) items per driven
-// device (the rule of jubjub_schnorr_amd/sharding.py), each block is staged, verified and copied back on
-// its device's stream, and the tallies are summed with one RCCL all-reduce.  With one device this is
-// stage -> launch -> copy back.
+// Host-buffer calls.  The batch is cut into one contiguous block of ceil(n / devices) items per driven
+// device (the rule of jubjub_schnorr_amd/sharding.py).  Each block runs as a pipeline of chunks of at least
+// HOST_CHUNK_ITEMS items: chunk c+1 is uploaded on the device's copy stream while chunk c is being verified
+// on its compute stream, and the statuses of chunk c-1 travel back meanwhile.  Inputs, statuses and the
+// events live in a per-device staging arena that only grows.  The tallies accumulate over the chunks and are
+// summed over the devices with one RCCL all-reduce at the end.
 struct host_col { const uint8_t* p; size_t width; };
+constexpr size_t HOST_CHUNK_ITEMS = size_t(1) << 18;
+constexpr size_t HOST_MAX_CHUNKS = 32;
+
+bool g_keep_tally = false;   // set while run_host issues the chunks of one batch: the counters accumulate
+
+int ensure_stage(size_t bytes) {
+    if (bytes <= g->stage_bytes) return JJS_OK;
+    if (g->stage) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(g->stage));
+        g->stage = nullptr; g->stage_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&g->stage, bytes));
+    g->stage_bytes = bytes;
+    return JJS_OK;
+}
 
 template <size_t K, typename Launch>
 int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tally[4], Launch&& launch) {
@@ -483,11 +504,13 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
     std::vector<device_state*> targets;
     if (L.devs.size() == 1) targets.push_back(g); else targets = L.devs;
     const size_t nd = targets.size();
-    struct block { staged in[K]; staged st; size_t lo = 0, hi = 0; };
+    struct block { size_t lo = 0, hi = 0, chunk = 0, chunks = 0; uint8_t* in[K] = {}; uint8_t* st = nullptr; };
     std::vector<block> blocks(nd);
     device_restore restore;
+    struct keep_tally_scope { keep_tally_scope() { g_keep_tally = true; } ~keep_tally_scope() { g_keep_tally = false; } } keep;
     const size_t per = (n + nd - 1) / nd;
     int rc;
+    size_t max_chunks = 0;
     for (size_t d = 0; d < nd; ++d) {
         g = targets[d];
         HIP_TRY(hipSetDevice(g->device));
@@ -495,13 +518,48 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
         const size_t nl = b.hi - b.lo;
-        const void* dp[K];
-        for (size_t k = 0; k < K; ++k) {
-            if ((rc = b.in[k].up(cols[k].p ? cols[k].p + b.lo * cols[k].width : nullptr, nl * cols[k].width, g->stream))) return rc;
-            dp[k] = b.in[k].d;
+        b.chunk = HOST_CHUNK_ITEMS;
+        if (nl > b.chunk * HOST_MAX_CHUNKS) b.chunk = ((nl + HOST_MAX_CHUNKS - 1) / HOST_MAX_CHUNKS + 255) & ~size_t(255);
+        b.chunks = (nl + b.chunk - 1) / b.chunk;
+        if (b.chunks > max_chunks) max_chunks = b.chunks;
+        size_t bytes = 0;
+        for (size_t k = 0; k < K; ++k) bytes += (nl * cols[k].width + 255) & ~size_t(255);
+        bytes += (nl + 255) & ~size_t(255);
+        if ((rc = ensure_stage(bytes ? bytes : 256))) return rc;
+        uint8_t* p = g->stage;
+        for (size_t k = 0; k < K; ++k) { b.in[k] = p; p += (nl * cols[k].width + 255) & ~size_t(255); }
+        b.st = p;
+        // the arena and the counters may still be in use by the previous call's last launches
+        HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
+        HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
+    }
+    for (size_t c = 0; c <= max_chunks; ++c) {
+        for (size_t d = 0; d < nd; ++d) {
+            g = targets[d];
+            block& b = blocks[d];
+            if (c > b.chunks || b.chunks == 0) continue;
+            HIP_TRY(hipSetDevice(g->device));
+            if (c < b.chunks) {
+                const size_t off = c * b.chunk, len = (off + b.chunk < b.hi - b.lo) ? b.chunk : (b.hi - b.lo - off);
+                const void* dp[K];
+                for (size_t k = 0; k < K; ++k) {
+                    const size_t w = cols[k].width;
+                    HIP_TRY(hipMemcpyAsync(b.in[k] + off * w, cols[k].p + (b.lo + off) * w, len * w, hipMemcpyHostToDevice,
+                                           g->copy_stream));
+                    dp[k] = b.in[k] + off * w;
+                }
+                HIP_TRY(hipEventRecord(g->chunk_up[c], g->copy_stream));
+                HIP_TRY(hipStreamWaitEvent(g->stream, g->chunk_up[c], 0));
+                if ((rc = launch(dp, len, (void*)(b.st + off), (void*)g->tally, (void*)g->stream))) return rc;
+                HIP_TRY(hipEventRecord(g->chunk_done[c], g->stream));
+            }
+            if (c > 0 && status) {            // statuses of the previous chunk, behind this chunk's upload
+                const size_t off = (c - 1) * b.chunk, len = (off + b.chunk < b.hi - b.lo) ? b.chunk : (b.hi - b.lo - off);
+                HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->chunk_done[c - 1], 0));
+                HIP_TRY(hipMemcpyAsync(status + b.lo + off, b.st + off, len, hipMemcpyDeviceToHost, g->copy_stream));
+            }
         }
-        if ((rc = b.st.alloc(nl))) return rc;
-        if ((rc = launch(dp, nl, b.st.d, (void*)g->tally, (void*)g->stream))) return rc;
     }
     if (nd > 1 && L.comms_up)
         if ((rc = allreduce_tallies())) return rc;
@@ -509,14 +567,12 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
     for (size_t d = 0; d < nd; ++d) {
         g = targets[d];
         HIP_TRY(hipSetDevice(g->device));
-        const block& b = blocks[d];
-        if (status && b.hi > b.lo)
-            HIP_TRY(hipMemcpyAsync(status + b.lo, b.st.d, b.hi - b.lo, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipMemcpyAsync(t[d], g->tally, sizeof(t[d]), hipMemcpyDeviceToHost, g->stream));
     }
     for (size_t d = 0; d < nd; ++d) {
         HIP_TRY(hipSetDevice(targets[d]->device));
         HIP_TRY(hipStreamSynchronize(targets[d]->stream));
+        HIP_TRY(hipStreamSynchronize(targets[d]->copy_stream));
     }
     if (tally) {
         for (int i = 0; i < 4; ++i) tally[i] = t[0][i];

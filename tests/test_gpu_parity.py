@@ -228,6 +228,11 @@ def test_full_size_properties(eng, scheme, log2n):
     sel = torch.from_numpy(np.random.default_rng(5).choice(n, 2048, replace=False)).cuda()
     sample = {k: host(v[sel]) for k, v in arrs.items()}
     assert host(st[sel]).tolist() == oracle_verify(scheme, sample).tolist()
+    # the blocking host-buffer call pipelines the batch in chunks of 2^18 items: ragged multi-chunk batch, same results
+    nh = (1 << 19) + 777
+    st_h, tally_h = eng.verify(scheme, *[host(arrs[k][:nh]) for k in ARG_ORDER[scheme]])
+    assert (st_h == host(expect[:nh])).all()
+    assert tally_h.tolist() == [int((expect[:nh] == k).sum()) for k in range(4)]
 
 
 # ---- wire formats ---------------------------------------------------------------------
