@@ -254,7 +254,8 @@ class Engine:
         nbytes = self._lib.jjs_debug_comb_table_bytes()
         out = np.empty(nbytes // 4, np.uint32)
         _ffi.check(self._lib.jjs_debug_comb_table(which, out.ctypes.data_as(ctypes.c_void_p)), "jjs_debug_comb_table")
-        return out.reshape(32, 256, 28)
+        bits = 16 if nbytes == 16 * 65536 * 112 else 8          # digits of the fixed-base comb (csrc/verify_core.h)
+        return out.reshape(256 // bits, 1 << bits, 28)
 
     def sync(self):
         _ffi.check(self._lib.jjs_stream_sync(self._stream()), "jjs_stream_sync")

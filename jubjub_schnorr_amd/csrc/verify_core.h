@@ -15,10 +15,12 @@
 // Method (bit-exact in RESULT, not in method):
 //   * fixed generator: half-size scalars (a = b*c mod r, |a|,|b| < 2^126 from a truncated Euclid) turn
 //     the equation into (b*u)*G + a*PK - b*R == O: 124 shared doublings, signed 4-bit windows over two
-//     per-lane tables {0..8}*PK, {0..8}*R in a global-memory workspace (144 B per entry), and an 8-bit
-//     fixed-base comb for G / G' (32 mixed additions from a 917 KB L2-resident table).
+//     per-lane tables {0..8}*PK, {0..8}*R in a global-memory workspace (144 B per entry), and a 16-bit
+//     fixed-base comb for G / G' (16 mixed additions gathered from a 117 MB table).
 //   * var-gen: u*Gen + c*PK by Straus over two per-lane tables, 252 shared doublings.
-//   * subgroup check: order-8 Tate pairing residue test, one exponentiation per point instead of [r]P.
+//   * subgroup check: order-8 Tate pairing residue test instead of [r]P -- one exponentiation per
+//     fixed-generator equation (on a combination of its two points) in the first pass, one per point in
+//     the resolve pass for the items the first pass cannot decide (see verify_item).
 #pragma once
 #include "ed29.h"
 #include "hades29.h"
@@ -65,7 +67,13 @@ constexpr int TABLE_ENTRIES = 9;                 // {0..8} * P
 constexpr int ENTRY_WORDS = 36;                  // 4 coordinates x 9 limbs
 constexpr int TABLE_WORDS = TABLE_ENTRIES * ENTRY_WORDS;
 constexpr int WS_WORDS_PER_LANE = 2 * TABLE_WORDS;
-constexpr int COMB_WINDOWS = 32, COMB_ENTRIES = 256;
+// Fixed-base comb: the 256-bit scalar is cut into digits of JJS_COMB_BITS bits; one table row per digit position.
+#ifndef JJS_COMB_BITS
+#define JJS_COMB_BITS 16
+#endif
+constexpr int COMB_BITS = JJS_COMB_BITS;
+static_assert(COMB_BITS == 8 || COMB_BITS == 16, "digits must tile a 32-bit word");
+constexpr int COMB_WINDOWS = 256 / COMB_BITS, COMB_ENTRIES = 1 << COMB_BITS;
 constexpr int COMB_ENTRY_WORDS = 28;             // 3 coordinates x 9 limbs, padded to 7 x 16 B
 constexpr size_t COMB_TABLE_WORDS = (size_t)COMB_WINDOWS * COMB_ENTRIES * COMB_ENTRY_WORDS;
 
@@ -438,8 +446,9 @@ JJS_HD bool point_on_curve_not_identity(const fe_n& u, const fe_n& v) {
 
 JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
     for (int i = 0; i < COMB_WINDOWS; ++i) {
-        uint32_t byte = (word_at(k, i >> 2) >> ((i & 3) * 8)) & 255u;
-        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + byte) * COMB_ENTRY_WORDS);
+        constexpr int per_word = 32 / COMB_BITS;
+        const uint32_t digit = (word_at(k, i / per_word) >> ((i % per_word) * COMB_BITS)) & (uint32_t)(COMB_ENTRIES - 1);
+        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
         uint32_t w[COMB_ENTRY_WORDS];
 #pragma unroll
         for (int k4 = 0; k4 < COMB_ENTRY_WORDS / 4; ++k4) { u32x4 v = p[k4]; w[4 * k4] = v.x; w[4 * k4 + 1] = v.y; w[4 * k4 + 2] = v.z; w[4 * k4 + 3] = v.w; }
@@ -643,17 +652,17 @@ JJS_HD uint32_t resolve_item(const verify_params& P, uint64_t item, bool eq_held
     return resolve_status(valid, eq_held);
 }
 
-// ---- fixed-base comb table: entry (i, b) = b * 256^i * Base as an affine cached addend ------------
+// ---- fixed-base comb table: entry (i, b) = b * 2^(COMB_BITS*i) * Base as an affine cached addend ----
 JJS_HD fe_n fq_inverse(const fe_n& a) { return fq_pow_schedule(a, JJS_INV_SW, JJS_INV_SW_STEPS, JJS_INV_SW_TRAILING); }
 
-JJS_HD void build_comb_entry(uint32_t* table, const uint32_t (*base)[9], int i, int b) {
+JJS_HD void comb_entry_words(uint32_t* dst, const uint32_t (*base)[9], int i, int b) {
     fe_n bu = fq_as<1, 2>(fe_from_const<1, 1>(base[0])), bv = fq_as<1, 2>(fe_from_const<1, 1>(base[1]));
     ext_pt p = ext_from_affine(bu, bv);
     niels_pt n = to_niels(p);
     ext_pt acc = ext_identity();
-    for (int bit = 8 * i + 7; bit >= 0; --bit) {
+    for (int bit = COMB_BITS * i + COMB_BITS - 1; bit >= 0; --bit) {
         acc = ext_double(acc, true);
-        bool set = bit >= 8 * i && ((b >> (bit - 8 * i)) & 1);
+        bool set = bit >= COMB_BITS * i && ((b >> (bit - COMB_BITS * i)) & 1);
         niels_pt addend = niels_select(set, n, niels_identity());
         acc = ext_add_niels(acc, addend, false, true);
     }
@@ -662,9 +671,11 @@ JJS_HD void build_comb_entry(uint32_t* table, const uint32_t (*base)[9], int i, 
     fe_n ypx = fq_reduce(fq_norm(fq_add(y, x)));
     fe_n ymx = fq_mul(fq_norm(fq_sub(y, x)), fq_one());      // times 1: same value, back below 2q
     fe_n t2d = fq_mul(fq_mul(x, y), fe_from_const<1, 1>(JJS_D2));
-    uint32_t* dst = table + ((size_t)i * COMB_ENTRIES + b) * COMB_ENTRY_WORDS;
     for (int k = 0; k < 9; ++k) { dst[k] = ypx.l[k]; dst[9 + k] = ymx.l[k]; dst[18 + k] = t2d.l[k]; }
     dst[27] = 0;
+}
+JJS_HD void build_comb_entry(uint32_t* table, const uint32_t (*base)[9], int i, int b) {
+    comb_entry_words(table + ((size_t)i * COMB_ENTRIES + b) * COMB_ENTRY_WORDS, base, i, b);
 }
 
 }  // namespace jjs

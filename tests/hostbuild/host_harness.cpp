@@ -14,15 +14,47 @@ using namespace jjs;
 static std::vector<uint32_t> g_comb_g, g_comb_gn;
 alignas(16) static uint32_t g_tag[8];
 
+// Comb tables for the CPU build.  The device builds every entry from scratch in its own lane
+// (build_comb_entry); one CPU thread fills a row by repeated addition of 2^(COMB_BITS*i)*Base and one
+// batched inversion instead -- the same values (tests compare sampled entries of both with the oracle,
+// and a handful of entries here with build_comb_entry itself).
+static void fill_comb_row(uint32_t* table, const uint32_t (*base)[9], int i) {
+    fe_n bu = fq_as<1, 2>(fe_from_const<1, 1>(base[0])), bv = fq_as<1, 2>(fe_from_const<1, 1>(base[1]));
+    ext_pt step = ext_from_affine(bu, bv);
+    for (int k = 0; k < COMB_BITS * i; ++k) step = ext_double(step, true);
+    const niels_pt nstep = to_niels(step);
+    std::vector<ext_pt> pts(COMB_ENTRIES);
+    std::vector<fe_n> prefix(COMB_ENTRIES);
+    ext_pt acc = ext_identity();
+    fe_n run = fe_n_one();
+    for (int b = 0; b < COMB_ENTRIES; ++b) {
+        pts[b] = acc;
+        prefix[b] = run;                       // product of Z_0 .. Z_{b-1}
+        run = fq_mul(run, acc.z);
+        acc = ext_add_niels(acc, nstep, false, true);
+    }
+    fe_n inv = fq_inverse(run);                // 1 / (Z_0 ... Z_{last})
+    for (int b = COMB_ENTRIES - 1; b >= 0; --b) {
+        fe_n zi = fq_mul(inv, prefix[b]);
+        inv = fq_mul(inv, pts[b].z);
+        fe_n x = fq_mul(pts[b].x, zi), y = fq_mul(pts[b].y, zi);
+        fe_n ypx = fq_reduce(fq_norm(fq_add(y, x)));
+        fe_n ymx = fq_mul(fq_norm(fq_sub(y, x)), fq_one());
+        fe_n t2d = fq_mul(fq_mul(x, y), fe_from_const<1, 1>(JJS_D2));
+        uint32_t* dst = table + ((size_t)i * COMB_ENTRIES + b) * COMB_ENTRY_WORDS;
+        for (int k = 0; k < 9; ++k) { dst[k] = ypx.l[k]; dst[9 + k] = ymx.l[k]; dst[18 + k] = t2d.l[k]; }
+        dst[27] = 0;
+    }
+}
+
 static void ensure_tables() {
     if (!g_comb_g.empty()) return;
     g_comb_g.resize(COMB_TABLE_WORDS);
     g_comb_gn.resize(COMB_TABLE_WORDS);
-    for (int i = 0; i < COMB_WINDOWS; ++i)
-        for (int b = 0; b < COMB_ENTRIES; ++b) {
-            build_comb_entry(g_comb_g.data(), JJS_G, i, b);
-            build_comb_entry(g_comb_gn.data(), JJS_GN, i, b);
-        }
+    for (int i = 0; i < COMB_WINDOWS; ++i) {
+        fill_comb_row(g_comb_g.data(), JJS_G, i);
+        fill_comb_row(g_comb_gn.data(), JJS_GN, i);
+    }
     memcpy(g_tag, JJS_DOUBLE_TAG_WORDS, 32);
 }
 
@@ -179,6 +211,20 @@ int jjs_host_raw_dot5(const uint32_t* t, int row, size_t n, uint32_t* out_dot, u
         memcpy(out_small + 9 * i, s.l, 36);
     }
     return 0;
+}
+int jjs_host_comb_bits(void) { return COMB_BITS; }
+// the device's per-entry builder on one entry: 1 if it equals the row-filled table entry
+int jjs_host_comb_entry_matches_device_builder(int which, int i, int b) {
+    ensure_tables();
+    uint32_t scratch[COMB_ENTRY_WORDS];
+    comb_entry_words(scratch, which ? JJS_GN : JJS_G, i, b);
+    const uint32_t* t = (which ? g_comb_gn.data() : g_comb_g.data()) + ((size_t)i * COMB_ENTRIES + b) * COMB_ENTRY_WORDS;
+    for (int c = 0; c < 3; ++c) {
+        fe_n f1, f2;
+        for (int k = 0; k < 9; ++k) { f1.l[k] = t[9 * c + k]; f2.l[k] = scratch[9 * c + k]; }
+        if (!fq_eq(f1, f2)) return 0;
+    }
+    return 1;
 }
 // comb table entry -> affine point bytes (u || v), recovered from the cached form
 int jjs_host_comb_entry(int which, int i, int b, uint8_t* out_ypx_ymx_t2d) {

@@ -72,6 +72,14 @@ def point_flags(P):
     load().jjs_host_point_flags(_p(P), ctypes.c_size_t(len(P)), _p(out)); return out
 
 
+def comb_bits():
+    return load().jjs_host_comb_bits()
+
+
+def comb_entry_matches_device_builder(which, i, b):
+    return bool(load().jjs_host_comb_entry_matches_device_builder(which, i, b))
+
+
 def comb_entry(which, i, b):
     out = np.empty(96, np.uint8)
     load().jjs_host_comb_entry(which, i, b, _p(out)); return out

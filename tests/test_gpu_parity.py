@@ -81,8 +81,11 @@ def test_comb_tables(eng):
     RPI = pow(1 << 261, -1, o.Q)
     for which, base in ((0, o.G), (1, o.G_NUMS)):
         tab = eng.debug_comb_table(which)
-        for i, b in ((0, 0), (0, 1), (0, 255), (1, 1), (5, 77), (17, 128), (31, 1), (31, 15)):
-            p = o.mul(base, b << (8 * i)) if b else o.IDENTITY
+        windows, entries = tab.shape[0], tab.shape[1]
+        bits = entries.bit_length() - 1
+        for i, b in ((0, 0), (0, 1), (0, entries - 1), (1, 1), (5, 77), (windows // 2, entries // 2), (windows - 1, 1),
+                     (windows - 1, 15), (windows - 1, entries - 3)):
+            p = o.mul(base, b << (bits * i)) if b else o.IDENTITY
             e = tab[i, b]
             val = [sum(int(x) << (29 * j) for j, x in enumerate(e[9 * c:9 * c + 9])) * RPI % o.Q for c in range(3)]
             assert val == [(p[1] + p[0]) % o.Q, (p[1] - p[0]) % o.Q, 2 * o.D * p[0] * p[1] % o.Q]

@@ -56,13 +56,17 @@ def test_point_flags_all_cosets():
 
 
 def test_comb_tables_are_multiples_of_generators():
+    bits = hl.comb_bits()
+    top, last = (1 << bits) - 1, 256 // bits - 1
     for which, base in ((0, o.G), (1, o.G_NUMS)):
-        for i, b in ((0, 0), (0, 1), (0, 255), (1, 1), (7, 200), (31, 1), (31, 15)):
-            p = o.mul(base, b << (8 * i)) if b else o.IDENTITY
+        for i, b in ((0, 0), (0, 1), (0, top), (1, 1), (last // 2, 200), (last // 2, top - 5), (last, 1), (last, 15)):
+            p = o.mul(base, b << (bits * i)) if b else o.IDENTITY
             e = hl.comb_entry(which, i, b)
             ypx, ymx, t2d = (to_int(e[32 * k:32 * k + 32]) for k in range(3))
             assert ypx == (p[1] + p[0]) % o.Q and ymx == (p[1] - p[0]) % o.Q
             assert t2d == 2 * o.D * p[0] * p[1] % o.Q
+            # the per-entry builder the device runs gives the same entry as the row filler of the CPU harness
+            assert hl.comb_entry_matches_device_builder(which, i, b)
 
 
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
