@@ -22,6 +22,8 @@
 //     fixed-generator equation (on a combination of its two points) in the first pass, one per point in
 //     the resolve pass for the items the first pass cannot decide (see verify_item).
 #pragma once
+#include <cmath>
+
 #include "ed29.h"
 #include "hades29.h"
 
@@ -310,19 +312,97 @@ JJS_HD uint64_t bits64_at(const uint32_t (&x)[8], int pos) {
     return pos < 0 ? (v << (-pos)) : v;
 }
 
-// Euclid on (r, c), truncated at the first remainder below 2^126.  Each pass removes q' * r1 from r0 for a
-// partial quotient q' <= floor(r0 / r1) estimated from the leading 63 bits in double precision (clamped
-// to 31 significant bits, at least 1), so any pass is a valid step of the extended Euclidean algorithm and the
-// invariant r0*|t1| + r1*|t0| = r holds throughout; a swap happens only when the remainder has dropped
-// below r1.  ~75 passes instead of ~190 single-bit steps; the loop runs until the slowest lane of the
-// wave is done.
+JJS_HD double rcp_estimate(double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(y);      // 1 ulp is enough: the quotient estimate is corrected below
+#else
+    return 1.0 / y;
+#endif
+}
+
+// Lehmer's inner loop: up to LEHMER_STEPS consecutive steps of Euclid's algorithm, decided on the leading
+// 52 bits of the two remainders alone.  x >= y are those leading bits (r0 = x*2^p + e0, r1 = y*2^p + e1,
+// 0 <= e < 2^p) held as doubles (integers below 2^53: every operation here is exact).  With cofactors
+// X_i = (-1)^i (u_i r0 - v_i r1) the true remainder is X_i = x_i 2^p + d_i, |d_i| < c_i 2^p, c_i = max(u_i, v_i),
+// so a step with quotient q = floor(x_{i-1} / x_i) is the true Euclid step (0 <= X_{i+1} < X_i) whenever
+//     x_{i+1} >= c_{i+1}   and   x_i - x_{i+1} >= c_i + c_{i+1},
+// and the remainder it divides by is still at least 2^126 (the stopping rule of half_size_scalars) whenever
+//     x_i >= th + c_i,  th = 2^(126 - p)  (1 when p > 126).
+// A step that cannot be certified ends the lane's run; the caller applies the certified ones to the full
+// numbers and comes back with fresh leading bits (or takes one full-precision step if there were none).
+constexpr int LEHMER_STEPS = 20;
+struct lehmer_run {
+    uint32_t u0, v0, u1, v1;   // (X_k, X_{k+1}) = +-(u0 r0 - v0 r1), -+(u1 r0 - v1 r1); all below 2^26
+    uint32_t steps;            // k
+};
+JJS_HD lehmer_run lehmer_steps(double x, double y, double th, bool live) {
+    double u0 = 1.0, v0 = 0.0, u1 = 0.0, v1 = 1.0;
+    uint32_t steps = 0;
+    for (int k = 0; k < LEHMER_STEPS; ++k) {
+        const double c1 = u1 > v1 ? u1 : v1;
+        bool ok = live && y >= th + c1;
+        const double ys = ok ? y : 1.0;
+        double q = ::floor(x * rcp_estimate(ys));
+        double xn = ::fma(-q, ys, x);                 // exact; the estimate is off by at most one when q < 2^26
+        const bool low = xn < 0.0, high = xn >= ys;
+        q = low ? q - 1.0 : (high ? q + 1.0 : q);
+        xn = low ? xn + ys : (high ? xn - ys : xn);
+        const double un = ::fma(q, u1, u0), vn = ::fma(q, v1, v0);
+        const double cn = un > vn ? un : vn;
+        ok = ok && q < 67108864.0 && cn < 67108864.0 && xn >= cn && (ys - xn) >= cn + c1;
+        x = ok ? ys : x;
+        y = ok ? xn : y;
+        u0 = ok ? u1 : u0; v0 = ok ? v1 : v0;
+        u1 = ok ? un : u1; v1 = ok ? vn : v1;
+        steps += ok ? 1u : 0u;
+        live = ok;
+    }
+    lehmer_run r;
+    r.u0 = (uint32_t)u0; r.v0 = (uint32_t)v0; r.u1 = (uint32_t)u1; r.v1 = (uint32_t)v1; r.steps = steps;
+    return r;
+}
+// m1 * a - m2 * b for 8-word a, b and 32-bit m1, m2, known to lie in [0, 2^256)
+JJS_HD void mul_sub_words(uint32_t (&out)[8], uint32_t m1, const uint32_t (&a)[8], uint32_t m2, const uint32_t (&b)[8]) {
+    uint64_t ca = 0, cb = 0;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ca += (uint64_t)m1 * a[i];
+        cb += (uint64_t)m2 * b[i];
+        const uint64_t d = (uint64_t)(uint32_t)ca - (uint32_t)cb - borrow;
+        out[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+        ca >>= 32; cb >>= 32;
+    }
+}
+// m1 * a + m2 * b for 4-word a, b (the result fits 4 words)
+JJS_HD void mul_add_words(uint32_t (&out)[4], uint32_t m1, const uint32_t (&a)[4], uint32_t m2, const uint32_t (&b)[4]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t p = (uint64_t)m1 * a[i] + (uint32_t)carry;
+        const uint64_t s2 = (uint64_t)m2 * b[i] + (uint32_t)p;
+        out[i] = (uint32_t)s2;
+        carry = (carry >> 32) + (p >> 32) + (s2 >> 32);
+    }
+}
+
+// Euclid on (r, c), truncated at the first remainder below 2^126: a = that remainder, b = its cofactor of c
+// (a = b*c mod r, a, |b| < 2^126).  Each pass first runs Lehmer's inner loop on the leading 52 bits (about 15
+// quotients per pass at ~30 instructions each, see lehmer_steps) and applies the resulting 2x2 matrix to the
+// full numbers; a lane for which no step could be certified (a quotient of 2^26 or more, a remainder within
+// 2^p of 2^126: adversarial c only) takes one full-precision step instead: q' * r1 is removed from r0 for a
+// partial quotient q' <= floor(r0 / r1) estimated from the leading 63 bits in double precision (clamped to 31
+// significant bits, at least 1), and a swap happens only when the remainder has dropped below r1.  Every pass
+// is a sequence of true Euclid steps, so the invariant r0*|t1| + r1*|t0| = r holds throughout and the result
+// is the one of the textbook algorithm.  ~7 passes; the loop runs until the slowest lane of the wave is done.
 JJS_HD half_scalars half_size_scalars(const words8& c) {
     uint32_t r0[8], r1[8], t0[4] = {0, 0, 0, 0}, t1[4] = {1, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 8; ++i) { r0[i] = JJS_FR_WORDS[i]; r1[i] = c.w[i]; }
     bool neg = false;   // sign of t1; t0 always has the opposite sign (or is zero)
-    // Worst case (all quotients 1, Fibonacci-like) is ~185 passes; the bound only guarantees that every wave
-    // leaves the loop whatever happens.
+    // The bound only guarantees that every wave leaves the loop whatever happens (each pass makes progress
+    // in every active lane; the worst case, all quotients 1, is 185 steps).
     for (int pass = 0; pass < 512; ++pass) {
         words8 w1;
 #pragma unroll
@@ -332,11 +412,36 @@ JJS_HD half_scalars half_size_scalars(const words8& c) {
         words8 w0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) w0.w[i] = r0[i];
+        const int len0 = bitlen256(w0);
+        // ---- Lehmer run on the leading 52 bits of r0 and the bits of r1 at the same position -------------
+        bool single;   // this lane is active and no step could be certified: one full-precision step below
+        {
+            const int p = len0 - 52;                                   // >= 75: r0 >= r1 >= 2^126 in active lanes
+            const double x = (double)(bits64_at(r0, len0 - 64) >> 12), y = (double)(bits64_at(r1, len0 - 64) >> 12);
+            const int sh = 126 - p;
+            const double th = sh > 0 ? (double)(1ull << sh) : 1.0;     // sh <= 51
+            const lehmer_run L = lehmer_steps(x, y, th, active);
+            const bool odd = (L.steps & 1u) != 0;
+            uint32_t A[8], B[8], n0[8], n1[8], m0[4], m1[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { A[i] = odd ? r1[i] : r0[i]; B[i] = odd ? r0[i] : r1[i]; }
+            mul_sub_words(n0, odd ? L.v0 : L.u0, A, odd ? L.u0 : L.v0, B);      // X_k
+            mul_sub_words(n1, odd ? L.u1 : L.v1, B, odd ? L.v1 : L.u1, A);      // X_{k+1}
+            mul_add_words(m0, L.u0, t0, L.v0, t1);
+            mul_add_words(m1, L.u1, t0, L.v1, t1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { r0[i] = n0[i]; r1[i] = n1[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t0[i] = m0[i]; t1[i] = m1[i]; }
+            neg = odd ? !neg : neg;
+            single = active && L.steps == 0;        // then the matrix was the identity: w0, w1 still hold r0, r1
+        }
+        if (!wave_any(single)) continue;
         // leading 63 bits of r0 and of r1, each at its own position: r0 >= A * 2^p0 and r1 < (B + 1) * 2^p1,
         // so r0 / r1 > A / (B + 1) * 2^(p0 - p1)
         const int p0 = bitlen256(w0) - 63, p1 = bitlen256(w1) - 63;
         const uint64_t A = bits64_at(r0, p0), B = bits64_at(r1, p1);
-        const int e = active ? p0 - p1 : 0;                       // >= 0 because r0 >= r1
+        const int e = single ? p0 - p1 : 0;                       // >= 0 because r0 >= r1
         double qd = ((double)A / ((double)B + 1.0)) * (1.0 - 1.0 / 1125899906842624.0);   // in (0.49, 2)
         // A quotient of 2^31 or more (adversarial c only) is taken as q * 2^k with q below 2^31: the
         // multiple removed is q * (r1 << k).  The shifter runs only when some lane of the wave needs it.
@@ -353,7 +458,7 @@ JJS_HD half_scalars half_size_scalars(const words8& c) {
         }
         uint32_t q = (uint32_t)qd;
         q = q ? q : 1u;                       // r0 >= r1 always, so one multiple can be removed
-        q = active ? q : 0u;
+        q = single ? q : 0u;
         // r0 -= q * x ; t0 += q * y
         uint32_t n0[8], m0[4];
         uint64_t carry = 0;
@@ -373,7 +478,7 @@ JJS_HD half_scalars half_size_scalars(const words8& c) {
             m0[i] = (uint32_t)carry;
             carry >>= 32;
         }
-        const bool swap = active && lt_words(n0, r1);
+        const bool swap = single && lt_words(n0, r1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t a = n0[i], b = r1[i];

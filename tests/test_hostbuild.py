@@ -103,7 +103,7 @@ def test_every_torsion_component_is_caught(scheme):
 def test_half_size_scalars():
     """a = b*c (mod r) with a, |b| < 2^126, for random and adversarial c."""
     rng = np.random.default_rng(12)
-    c = rand_mod(rng, 400, 1 << 250)
+    c = rand_mod(rng, 3000, 1 << 250)
     specials = [0, 1, 2, (1 << 126) - 1, 1 << 126, (1 << 126) + 1, (1 << 250) - 1, o.R_ORDER - 1, o.R_ORDER // 2,
                 (o.R_ORDER + 1) // 2, 1 << 127, 1 << 200, 3 << 248, o.R_ORDER - (1 << 126), (1 << 125) + 12345]
     for i, x in enumerate(specials):
@@ -117,6 +117,13 @@ def test_half_size_scalars():
             b = -b
         assert 0 <= a < 1 << 126 and 0 < abs(b) < 1 << 126, (i, a, b)
         assert (a - b * ci) % o.R_ORDER == 0, i
+        # and it is exactly where Euclid's algorithm on (r, c) first drops below 2^126: every step the
+        # implementation takes (single- or multi-quotient, on truncated operands) must be a true Euclid step
+        r0, r1, t0, t1 = o.R_ORDER, ci, 0, 1
+        while r1 >= 1 << 126:
+            q = r0 // r1
+            r0, r1, t0, t1 = r1, r0 - q * r1, t1, t0 - q * t1
+        assert (a, b) == (r1, t1), i
 
 
 def wire_point_cases(rng, n_random=64):
