@@ -8,7 +8,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjjs_gpu.so")
+# JJS_GPU_LIB: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
+LIB_PATH = os.environ.get("JJS_GPU_LIB") or os.path.join(HERE, "libjjs_gpu.so")
 
 _P, _Z, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 

@@ -128,7 +128,7 @@ JJS_HD void build_point_table(uint32_t* tab, const fe_n& u, const fe_n& v) {
     ext_pt acc = ext_double(p1, true);
     store_niels(tab + 2 * ENTRY_WORDS, to_niels(acc));
     for (int k = 3; k <= 8; ++k) {
-        acc = ext_add_niels(acc, n1, false, true);
+        acc = ext_add_affine_niels(acc, n1.ypx, n1.ymx, n1.t2d, true);     // n1 is affine (Z = 1): 7 products
         store_niels(tab + k * ENTRY_WORDS, to_niels(acc));
     }
 }
