@@ -27,6 +27,19 @@ JJS_HD fe_n sbox5(const fe<L, A>& x) {
 #endif
 }
 
+// The linear layer: st.s[i] = (sum_j S[i][j] * t[j]) / 2^29 with S[i][j] = JJS_HS_HANKEL[i + j].  On the
+// device one asm block (tools/gen_mont_asm.py: one accumulator chain per row, the 9 distinct matrix entries
+// as scalar operands); elsewhere five fq_lincomb_small calls.
+JJS_HD void hades_matrix(hades_state& o, const fe_n (&t)[5]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t* h = JJS_HS_HANKEL;
+    asm(JJS_HADES_MATRIX_ASM : JJS_HADES_MATRIX_OUTPUTS : JJS_HADES_MATRIX_INPUTS : JJS_HADES_MATRIX_CLOBBERS);
+#else
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o.s[i] = fq_lincomb_small<5>(JJS_HS_MAT[i], t);
+#endif
+}
+
 // The permutation (constants and derivation: scaled_hades_constants() in tools/gen_constants.py).
 // The MDS matrix is Cauchy, M[i][j] = F / (i + j + 5); with L = lcm(5..13) = 360360 it is (F/L) * S for a
 // matrix S of INTEGERS below 2^17, so a matrix row is 45 small multiply-adds plus one Montgomery row
@@ -50,8 +63,7 @@ JJS_HD void hades_permute(hades_state& st) {
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
             t[4] = fq_mul(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k]))), fe_from_const<1, 1>(JJS_HS_MU[k]));
         }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) st.s[i] = fq_lincomb_small<5>(JJS_HS_MAT[i], t);
+        hades_matrix(st, t);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) st.s[i] = fq_mul(st.s[i], fe_from_const<1, 1>(JJS_HS_LAMBDA_END));

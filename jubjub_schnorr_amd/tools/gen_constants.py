@@ -371,6 +371,9 @@ def main():
         assert hades_reference(st) == hades_scaled_model(st, rc_full, kap, mu, lam_end), "scaled Hades differs"
     L.append("// Hades with the small-integer matrix S = L / (i + j + 5), L = 360360 (scaled_hades_constants())")
     L.append("JJS_CONST uint32_t JJS_HS_MAT[5][5] = {" + ", ".join("{" + ", ".join(str(x) for x in row) + "}" for row in SMALL_S) + "};")
+    assert all(SMALL_S[i][j] == SMALL_S[0][i + j] if i + j < 5 else SMALL_S[i][j] == SMALL_S[i + j - 4][4] for i in range(5) for j in range(5))
+    hankel = [SMALL_S[0][k] if k < 5 else SMALL_S[k - 4][4] for k in range(9)]      # S[i][j] = hankel[i + j]
+    L.append("JJS_CONST uint32_t JJS_HS_HANKEL[9] = {" + ", ".join(str(x) for x in hankel) + "};")
     L.append("JJS_CONST uint32_t JJS_HS_RC_FULL[%d][5][9] = {" % N_FULL)
     L += ["  {" + ", ".join(limbs29(mont(x)) for x in row) + "}," for row in rc_full]
     L.append("};")

@@ -87,10 +87,51 @@ def emit(name, square):
     return out
 
 
+def hades_matrix():
+    """The linear layer of one Hades round as one block: out_i = (sum_j H[i+j] * in_j + m_i * q) / 2^29 for
+    i = 0..4 (fq_lincomb_small<5> five times; H = the 9 distinct entries of the Hankel matrix S, SGPR operands).
+    Operands: %[o<i>_<c>] 45 early-clobber outputs, %[t<j>_<c>] 45 inputs, %[h<k>] 9 scalars; clobbers as the
+    Montgomery blocks (accumulator v[36:37], quotient digit v18, q limbs s4..s11, mask s[12:13], vcc).
+    One accumulator chain per row: 53 multiply-adds + 21 shifts/masks, 74 instructions (written in C++ hipcc
+    restarts every column from zero and merges the carry with an extra 64-bit add: 81, plus the reloads of
+    25 separately held matrix entries)."""
+    L = []
+    for i in range(1, 9):
+        L.append("s_mov_b32 %s, 0x%x" % (SQ[i], QL[i]))
+    L.append("s_mov_b64 s[12:13], 0x1fffffff")
+    m = M[0]
+    for i in range(5):
+        for c in range(9):
+            for j in range(5):
+                addend = "0" if (c == 0 and j == 0) else ACC
+                L.append("v_mad_u64_u32 %s, vcc, %%[t%d_%d], %%[h%d], %s" % (ACC, j, c, i + j, addend))
+            if c == 0:
+                L += ["v_sub_u32 %s, 0, %s" % (m, ACC_LO), "v_and_b32 %s, 0x1fffffff, %s" % (m, m),
+                      "v_lshl_add_u64 %s, %s, 0, s[12:13]" % (ACC, ACC), "v_lshrrev_b64 %s, 29, %s" % (ACC, ACC)]
+            else:
+                L.append(mad(m, SQ[c]))
+                L += ["v_and_b32 %%[o%d_%d], 0x1fffffff, %s" % (i, c - 1, ACC_LO), "v_lshrrev_b64 %s, 29, %s" % (ACC, ACC)]
+        L.append("v_mov_b32 %%[o%d_8], %s" % (i, ACC_LO))
+    n_mad = sum(l.startswith("v_mad") for l in L)
+    assert n_mad == 5 * 53, n_mad
+    out = ["// Hades linear layer: %d instructions, %d v_mad_u64_u32" % (len(L), n_mad), "#define JJS_HADES_MATRIX_ASM \\"]
+    out += ['    "%s\\n\\t" \\' % l for l in L]
+    out[-1] = out[-1][:-2]
+    # operand lists for `hades_state& o` (outputs), `const fe_n (&t)[5]` (inputs) and `const uint32_t* h`
+    outs = ", ".join('[o%d_%d] "=&v"(o.s[%d].l[%d])' % (i, c, i, c) for i in range(5) for c in range(9))
+    ins = ", ".join('[t%d_%d] "v"(t[%d].l[%d])' % (j, c, j, c) for j in range(5) for c in range(9))
+    hs = ", ".join('[h%d] "s"(h[%d])' % (k, k) for k in range(9))
+    out.append("#define JJS_HADES_MATRIX_OUTPUTS " + outs)
+    out.append("#define JJS_HADES_MATRIX_INPUTS " + ins + ", " + hs)
+    out.append('#define JJS_HADES_MATRIX_CLOBBERS "vcc", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "v18", "v36", "v37"')
+    return out
+
+
 def main():
     T = ["// GENERATED by jubjub_schnorr_amd/tools/gen_mont_asm.py -- do not edit."]
     T += emit("JJS_MONT_MUL_ASM", False)
     T += emit("JJS_MONT_SQR_ASM", True)
+    T += hades_matrix()
     T.append('#define JJS_MONT_ASM_CLOBBERS "vcc", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", \\')
     T.append('    "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v36", "v37"')
     with open(OUT, "w") as f:
