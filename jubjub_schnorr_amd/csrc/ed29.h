@@ -56,18 +56,20 @@ JJS_HD niels_pt niels_select(bool c, const niels_pt& a, const niels_pt& b) {
 // E = 2XY is a product, not (X+Y)^2 - X^2 - Y^2: one multiply costs about what the two extra
 // subtractions and their carry propagation would, and keeps E below 4q.
 JJS_HD ext_pt ext_double(const ext_pt& p, bool need_t) {
+    // The inlined product overwrites its first operand, so an operand that is still needed afterwards costs a
+    // 9-register copy: each value below is the first operand of the LAST product that uses it.
+    auto e = fq_dbl(fq_mul_hot(p.x, p.y));         // 2XY             <2,4>   (copies X once)
     fe_n xx = fq_sqr_hot(p.x);
     fe_n yy = fq_sqr_hot(p.y);
     auto c2 = fq_dbl(fq_sqr_hot(p.z));             // 2Z^2            <2,4>
-    auto e = fq_dbl(fq_mul_hot(p.x, p.y));         // 2XY             <2,4>
     auto g = fq_add(yy, xx);                   // Y^2 + X^2       <2,4>
-    auto h = fq_norm(fq_sub(yy, xx));          // Y^2 - X^2       <1,5>
-    auto f = fq_norm(fq_sub(c2, h));           // 2Z^2 - (Y^2 - X^2)  <1,10>
+    auto h = fq_sub(yy, xx);                   // Y^2 - X^2       <3,5>: used in products only, no carry pass
+    auto f = fq_norm(fq_sub(fq_add(c2, xx), yy));   // 2Z^2 - (Y^2 - X^2) = (2Z^2 + X^2) - Y^2   <1,9>
     ext_pt r;
-    r.x = fq_mul_hot(e, f);
-    r.y = fq_mul_hot(g, h);
+    r.x = fq_mul_hot(e, f);                    // e survives only when T is wanted
     r.z = fq_mul_hot(f, h);
-    if (need_t) r.t = fq_mul_hot(e, g); else r.t = fe_n_zero();
+    r.y = fq_mul_hot(h, g);
+    if (need_t) r.t = fq_mul_hot(g, e); else r.t = fe_n_zero();
     return r;
 }
 
@@ -85,10 +87,10 @@ JJS_HD ext_pt ext_add_niels(const ext_pt& p, const niels_pt& n, bool neg, bool n
     auto g = fq_add(d, c);                         // <3,6>
     auto h = fq_add(b, a);                         // <2,4>
     ext_pt r;
-    r.x = fq_mul_hot(e, f);
-    r.y = fq_mul_hot(g, h);
+    r.x = fq_mul_hot(e, f);                    // same ordering rule as in ext_double
     r.z = fq_mul_hot(f, g);
-    if (need_t) r.t = fq_mul_hot(e, h); else r.t = fe_n_zero();
+    r.y = fq_mul_hot(g, h);
+    if (need_t) r.t = fq_mul_hot(h, e); else r.t = fe_n_zero();
     return r;
 }
 // P + N where N is affine (Z2 = 1): 7M (6M without T)
