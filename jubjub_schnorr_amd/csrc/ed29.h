@@ -96,19 +96,19 @@ JJS_HD ext_pt ext_add_niels(const ext_pt& p, const niels_pt& n, bool neg, bool n
 // P + N where N is affine (Z2 = 1): 7M (6M without T)
 JJS_HD ext_pt ext_add_affine_niels(const ext_pt& p, const fe_t& n_ypx, const fe_t& n_ymx, const fe_t& n_t2d,
                                    bool need_t) {
-    fe_n a = fq_mul(fq_sub(p.y, p.x), n_ymx);
-    fe_n b = fq_mul(fq_add(p.y, p.x), n_ypx);
-    fe_n c = fq_mul(p.t, n_t2d);
+    fe_n a = fq_mul_hot(fq_sub(p.y, p.x), n_ymx);
+    fe_n b = fq_mul_hot(fq_add(p.y, p.x), n_ypx);
+    fe_n c = fq_mul_hot(p.t, n_t2d);
     auto d = fq_dbl(p.z);                          // <2,4>
     auto e = fq_sub(b, a);
     auto f = fq_norm(fq_sub(d, c));
     auto g = fq_add(d, c);
     auto h = fq_add(b, a);
     ext_pt r;
-    r.x = fq_mul(e, f);
-    r.y = fq_mul(g, h);
-    r.z = fq_mul(f, g);
-    if (need_t) r.t = fq_mul(e, h); else r.t = fe_n_zero();
+    r.x = fq_mul_hot(e, f);
+    r.z = fq_mul_hot(f, g);
+    r.y = fq_mul_hot(g, h);
+    if (need_t) r.t = fq_mul_hot(h, e); else r.t = fe_n_zero();
     return r;
 }
 
