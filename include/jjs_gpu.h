@@ -144,6 +144,12 @@ int jjs_challenge_double_dev(const void* R, const void* R_prime, const void* PK,
 int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* c_out,
                              void* stream);
 
+/* ---- key derivation (reference `PublicKey::from(&SecretKey)` src/keys/public.rs:54-60, `PublicKeyDouble::from`
+ * src/keys/public/double.rs:47-57): PK[i] = sk[i] * G and, when PKp_out is not NULL, PK'[i] = sk[i] * G'
+ * (64 B affine each).  bad_out (nullable, n bytes) is set to 1 where sk[i] >= r.  Fixed-base comb, device
+ * pointers, asynchronous on `stream`.  NOT constant time: for public test material, not for live secrets. */
+int jjs_public_keys_dev(const void* sk, size_t n, void* PK_out, void* PKp_out, void* bad_out, void* stream);
+
 /* ---- signing: generator of synthetic inputs (NOT constant time, not for production keys) -------
  * sk, rnd: scalars < r; m: field element < q.  rnd is the RNG draw the reference's hedged nonce
  * mixes in (reference src/nonce.rs:32-44).  Outputs: u (n x 32), points (n x 64 affine). */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "jjs_debug_comb_table_bytes": [],
     "jjs_debug_comb_table": [_I, _P],
     "jjs_debug_rccl_selftest": [],
+    "jjs_public_keys_dev": [_P, _Z, _P, _P, _P, _P],
 }
 _RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
 

@@ -224,6 +224,19 @@ class Engine:
             return u, R, PK, Gen
         raise ValueError(scheme)
 
+    def public_keys(self, sk, double: bool = False):
+        """`PublicKey::from(&SecretKey)` for a batch (reference src/keys/public.rs:54-60): PK = sk*G, and with
+        `double` also PK' = sk*G' (src/keys/public/double.rs:47-57).  torch CUDA tensors; NOT constant time.
+        Returns (PK, bad) or (PK, PK', bad); bad[i] = 1 where sk[i] is not a canonical JubJubScalar."""
+        import torch
+        n = sk.shape[0]
+        new = lambda w: torch.empty((max(n, 1), w), dtype=torch.uint8, device=sk.device)[:n]  # noqa: E731
+        PK, PKp, bad = new(64), (new(64) if double else None), torch.empty(max(n, 1), dtype=torch.uint8, device=sk.device)[:n]
+        o = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and n else None  # noqa: E731
+        _ffi.check(self._lib.jjs_public_keys_dev(self._dev_ptr(sk, 32, n), n, o(PK), o(PKp), o(bad), self._stream()),
+                   "jjs_public_keys_dev")
+        return (PK, PKp, bad) if double else (PK, bad)
+
     # ---- primitives for parity tests ------------------------------------------------------------
     def debug_fq_mul(self, a, b):
         import torch

@@ -145,6 +145,21 @@ __global__ __launch_bounds__(BLOCK) void sign_kernel(sign_params P) {
     for (uint64_t item = gtid; item < P.n; item += total) sign_item(P, item, ws);
 }
 
+// PublicKey::from(&SecretKey) = sk * G (reference src/keys/public.rs:54-60) and the second half of
+// PublicKeyDouble::from (sk * G', src/keys/public/double.rs:47-57): fixed-base only, NOT constant time.
+__global__ __launch_bounds__(BLOCK) void derive_kernel(const uint8_t* sk, uint64_t n, const uint32_t* comb_g,
+                                                       const uint32_t* comb_gn, uint8_t* pk_out, uint8_t* pkp_out,
+                                                       uint8_t* bad) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    const fe_src s_sk{sk, 32, 0};
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < n; item += total) {
+        const words8 k = load_words(s_sk, item);
+        if (bad) bad[item] = words_lt(k, JJS_FR_WORDS) ? 0 : 1;       // non-canonical scalar (>= r)
+        store_point(pk_out, item, to_affine_words(comb_mul(comb_g, k)));
+        if (pkp_out) store_point(pkp_out, item, to_affine_words(comb_mul(comb_gn, k)));
+    }
+}
+
 // multisig passes: 0 map, 1 delinearisation, 2 aggregate key + a, 3 commitments, 4 RSa + c + u, 5 shares
 __global__ __launch_bounds__(BLOCK) void msig_kernel(msig_params P, int pass) {
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -984,6 +999,19 @@ int jjs_sign_vargen_dev(const void* sk, const void* gen_scalar, const void* rnd,
     P.rnd = (const uint8_t*)rnd; P.m = (const uint8_t*)m; P.n = n;
     P.u_out = (uint8_t*)u_out; P.R_out = (uint8_t*)R_out; P.PK_out = (uint8_t*)PK_out; P.Gen_out = (uint8_t*)Gen_out;
     return launch_sign(P, stream);
+}
+
+int jjs_public_keys_dev(const void* sk, size_t n, void* PK_out, void* PKp_out, void* bad_out, void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!all_ok(sk, PK_out) || (PKp_out && !aligned16(PKp_out))) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    size_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)sk,
+                       (uint64_t)n, g->comb_g, g->comb_gn, (uint8_t*)PK_out, (uint8_t*)PKp_out, (uint8_t*)bad_out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
 }
 
 // ---- debug primitives ------------------------------------------------------------------------------

@@ -238,6 +238,27 @@ def test_full_size_properties(eng, scheme, log2n):
     assert tally_h.tolist() == [int((expect[:nh] == k).sum()) for k in range(4)]
 
 
+def test_public_key_derivation(eng, reference_kat):
+    """PublicKey::from(&SecretKey): the reference's serde vectors give (sk, sk*G) and (sk*G, sk*G') for the same
+    seeded sk (tests/serde.rs:34-81); random scalars against the oracle; a non-canonical scalar is flagged."""
+    import torch
+    from jubjub_schnorr_amd import serde
+    v = reference_kat["serde_base58"]
+    sk_ref = serde.b58decode(v["serde_secret_key"])
+    rng = np.random.default_rng(8)
+    sks = [int.from_bytes(sk_ref, "little"), 1, 2, o.R_ORDER - 1] + [int(x) for x in rng.integers(1, 1 << 62, 20)]
+    sk = np.stack([fe_bytes(x) for x in sks] + [fe_bytes(o.R_ORDER)])            # last one: not canonical
+    PK, PKp, bad = (host(t) for t in eng.public_keys(dev(sk), double=True))
+    assert bad.tolist() == [0] * len(sks) + [1]
+    for i, x in enumerate(sks):
+        assert bytes(PK[i]) == pt_arr([o.mul(o.G, x)])[0].tobytes() and bytes(PKp[i]) == pt_arr([o.mul(o.G_NUMS, x)])[0].tobytes()
+    comp = host(eng.compress(dev(np.concatenate([PK[:1], PKp[:1]]))))
+    assert bytes(comp[0]) == serde.b58decode(v["serde_public_key"])
+    assert bytes(comp[0]) + bytes(comp[1]) == serde.b58decode(v["serde_public_key_double"])
+    PK1, bad1 = eng.public_keys(dev(sk))
+    assert torch.equal(PK1.cpu(), torch.from_numpy(PK)) and host(bad1).tolist() == bad.tolist()
+
+
 # ---- wire formats (SURVEY.md 8f-2) ---------------------------------------------------------------------
 def test_decompress_and_compress(eng):
     from test_hostbuild import wire_point_cases
