@@ -29,7 +29,7 @@ SQ = [None] + ["s%d" % (4 + i - 1) for i in range(1, 9)]      # q_1..q_8
 
 
 def prologue():
-    lines = ["v_mov_b64 %s, 0" % ACC]
+    lines = []                                  # the first multiply-add takes the literal 0 as its addend
     for i in range(1, 9):
         lines.append("s_mov_b32 %s, 0x%x" % (SQ[i], QL[i]))
     lines.append("s_mov_b64 s[12:13], 0x1fffffff")
@@ -47,8 +47,11 @@ def high_epilogue(k, a):
     return ["v_and_b32 %s, 0x1fffffff, %s" % (a(k - 9), ACC_LO), "v_lshrrev_b64 %s, 29, %s" % (ACC, ACC)]
 
 
-def mad(x, y):
-    return "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, ACC)
+ACC_HI = "v37"
+
+
+def mad(x, y, first=False):
+    return "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, "0" if first else ACC)
 
 
 def body(square):
@@ -65,15 +68,17 @@ def body(square):
                 if 2 * i < k:
                     L.append(mad(a(i), D[k - i]))
             if k % 2 == 0:
-                L.append(mad(a(k // 2), a(k // 2)))
+                L.append(mad(a(k // 2), a(k // 2), first=(k == 0)))
         else:
             for i in range(lo, hi + 1):
-                L.append(mad(a(i), b(k - i)))
+                L.append(mad(a(i), b(k - i), first=(k == 0)))
         for i in range(lo, hi + 1):
             if k - i >= 1 and i <= 8 and (k >= 9 or i < k):
                 L.append(mad(M[i], SQ[k - i]))
         L += low_epilogue(k) if k < 9 else high_epilogue(k, a)
-    L.append("v_mov_b32 %s, %s" % (a(8), ACC_LO))
+    # the last shift lands directly in limb 8: (acc >> 29) as one funnel shift instead of shift + move
+    assert L[-1].startswith("v_lshrrev_b64")
+    L[-1] = "v_alignbit_b32 %s, %s, %s, 29" % (a(8), ACC_HI, ACC_LO)
     return L
 
 
@@ -110,8 +115,9 @@ def hades_matrix():
                       "v_lshl_add_u64 %s, %s, 0, s[12:13]" % (ACC, ACC), "v_lshrrev_b64 %s, 29, %s" % (ACC, ACC)]
             else:
                 L.append(mad(m, SQ[c]))
-                L += ["v_and_b32 %%[o%d_%d], 0x1fffffff, %s" % (i, c - 1, ACC_LO), "v_lshrrev_b64 %s, 29, %s" % (ACC, ACC)]
-        L.append("v_mov_b32 %%[o%d_8], %s" % (i, ACC_LO))
+                L.append("v_and_b32 %%[o%d_%d], 0x1fffffff, %s" % (i, c - 1, ACC_LO))
+                L.append("v_lshrrev_b64 %s, 29, %s" % (ACC, ACC) if c < 8 else
+                         "v_alignbit_b32 %%[o%d_8], %s, %s, 29" % (i, ACC_HI, ACC_LO))
     n_mad = sum(l.startswith("v_mad") for l in L)
     assert n_mad == 5 * 53, n_mad
     out = ["// Hades linear layer: %d instructions, %d v_mad_u64_u32" % (len(L), n_mad), "#define JJS_HADES_MATRIX_ASM \\"]
