@@ -767,6 +767,7 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
+    P.decoded_points = 1;
     return verify_dev_common(P, status, tally, s);
 }
 static int wire_double_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
@@ -789,6 +790,7 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
                                     (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o);
     P.u = fe_src{(const uint8_t*)sig, 96, 0};
     P.pre_malformed = wire_bad();
+    P.decoded_points = 1;
     return verify_dev_common(P, status, tally, s);
 }
 static int wire_vargen_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
@@ -809,6 +811,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
+    P.decoded_points = 1;
     return verify_dev_common(P, status, tally, s);
 }
 typedef int (*wire_fn)(const void*, const void*, const void*, size_t, void*, void*, void*);
