@@ -274,7 +274,7 @@ def main():
             "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("decode_kernel + " if args.wire else "") + "verify_kernel + resolve_kernel (one batch)",
+                         "kernel": ("decode_kernel + " if args.wire else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
                          "kernel_ms": kernel_ms,
                          "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6"},
             "alu_roofline": alu,

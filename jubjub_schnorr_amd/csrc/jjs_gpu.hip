@@ -28,6 +28,14 @@ namespace {
 
 constexpr int BLOCK = 256;
 
+// First kernel of a batch: everything that does not need the window tables (see prepare_item).  No
+// per-lane workspace, about half the registers of verify_kernel: four waves per SIMD.
+__global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total)
+        store_prep(P.prep, P.n, item, prepare_item(P, item));
+}
+
 // second launch-bound argument: at least 2 waves per SIMD, i.e. at most 256 registers per lane
 __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -37,7 +45,7 @@ __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
         const uint64_t item = base + gtid;
         const bool active = item < P.n;
         const uint64_t it = active ? item : P.n - 1;
-        const uint32_t st = verify_item(P, it, ws, active);
+        const uint32_t st = finish_item(P, it, ws, load_prep(P.prep, P.n, it));
         if (active && st < ST_PENDING_EQ_FAILED && P.status) P.status[item] = (uint8_t)st;
         if (P.tally) {
 #pragma unroll
@@ -218,7 +226,7 @@ struct device_state {
     uint8_t* tag = nullptr;
     uint32_t* workspace = nullptr;
     unsigned long long* tally = nullptr;
-    int grid_verify = 0, grid_sign = 0, grid_resolve = 0;
+    int grid_verify = 0, grid_sign = 0, grid_resolve = 0, grid_prepare = 0;
     size_t ws_lanes = 0;
     hipEvent_t last_use = nullptr;  // end of the last launch that used the shared workspaces
     uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
@@ -231,6 +239,8 @@ struct device_state {
     size_t wire_items = 0;
     uint64_t* pending = nullptr;   // queue of the resolve pass: [0] = count, then one entry per queued item
     size_t pending_items = 0;
+    uint8_t* prep = nullptr;       // prepare_kernel -> verify_kernel records, 65 bytes per item (grow-only)
+    size_t prep_items = 0;
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
@@ -314,16 +324,33 @@ int ensure_pending(size_t n) {
     return JJS_OK;
 }
 
-// Two launches per batch: the verify pass, then the resolve pass over the items it queued (normally the
-// invalid ones only; the grid is sized for the batch, lanes without a queue entry leave at once).
+int ensure_prep(size_t n) {
+    if (n <= g->prep_items) return JJS_OK;
+    if (g->prep) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(g->prep));
+        g->prep = nullptr; g->prep_items = 0;
+    }
+    size_t cap = n < 65536 ? 65536 : n;
+    HIP_TRY(hipMalloc(&g->prep, cap * 65 + 64));
+    g->prep_items = cap;
+    return JJS_OK;
+}
+
+// Three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy), verify (the
+// equations; register-bound) and the resolve pass over the items verify queued (normally the invalid ones
+// only; the grid is sized for the batch, lanes without a queue entry leave at once).
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
     P.skip_phases = g_skip_phases;
     if (int rc = ensure_pending(P.n)) return rc;
+    if (int rc = ensure_prep(P.n)) return rc;
+    P.prep = g->prep;
     P.pending_count = reinterpret_cast<unsigned long long*>(g->pending);
     P.pending = g->pending + 2;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(g->pending, 0, sizeof(uint64_t), s));
+    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P);
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(g->grid_resolve, P.n * P.resolve_lanes)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
@@ -367,6 +394,9 @@ int init_device(device_state& d, int ordinal) {
     HIP_TRY(hipEventCreateWithFlags(&d.last_use, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(d.last_use, d.stream));
     int per_cu_v = 0, per_cu_s = 0, per_cu_m = 0, per_cu_r = 0;
+    int per_cu_p = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, prepare_kernel, BLOCK, 0));
+    d.grid_prepare = prop.multiProcessorCount * (per_cu_p < 1 ? 1 : per_cu_p) * 4;   // not persistent: a few blocks per slot
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, resolve_kernel, BLOCK, 0));
     d.grid_resolve = prop.multiProcessorCount * (per_cu_r < 1 ? 1 : per_cu_r);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
@@ -406,7 +436,7 @@ void free_device(device_state& d) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
     void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash,
-                    d.pending, d.stage};
+                    d.pending, d.stage, d.prep};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (d.last_use) (void)hipEventDestroy(d.last_use);

@@ -62,6 +62,7 @@ struct verify_params {
     uint32_t own_test_mask;          // bit k: points[k] gets its own subgroup test in the first pass
     uint32_t resolve_lanes;          // lanes per queued item in the resolve pass: 1, 2 or 4 >= points left to test
     uint32_t decoded_points;         // non-zero: every point was produced by decompress_point (on the curve)
+    uint8_t* prep;                   // 65 n bytes: what prepare_kernel hands to verify_kernel (see prep_record)
     uint64_t* pending;               // queue of items left to the resolve pass: item << 1 | equations held
     unsigned long long* pending_count;
 };
@@ -682,12 +683,28 @@ JJS_HD bool combined_subgroup_test(const eq_desc& E, uint64_t item, const half_s
 //    combined test to hold; anything else is pending;
 //  * per-item generator: PK and Gen get their own tests (own_test_mask); if the equation holds, R equals
 //    u*Gen + c*PK and is torsion-free with them; if it fails, R's test is pending.
-JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws, bool write_c = true) {
+// The work of a verification is cut in two so that the device can run each half at the occupancy its
+// register needs allow (prepare_kernel: four waves per SIMD, verify_kernel: two; jjs_gpu.hip):
+//   prepare_item : encodings, cheap point checks, own subgroup tests, challenge, half-size scalars, combined
+//                  subgroup tests -- everything except the window tables
+//   finish_item  : the equations and the verdict
+// prep_record is what passes between them (a device buffer of 65 bytes per item; locals on the CPU build).
+struct prep_record {
+    words8 c;            // challenge (250 bits)
+    half_scalars h;      // a, |b|, sign of b: zero for the per-item-generator scheme
+    bool malformed;      // an encoding out of range (status 3)
+    bool valid;          // every point on the curve and not the identity, own subgroup tests passed
+    bool proven;         // every combined subgroup test passed
+};
+
+JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true) {
+    prep_record r;
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
     bool malformed = !words_lt(u, JJS_FR_WORDS);
     if (P.pre_malformed) malformed = malformed || P.pre_malformed[item] != 0;
     for (uint32_t e = 0; e < P.n_hash; ++e) malformed = malformed || !words_lt(load_words(P.hash_in[e], item), JJS_Q_WORDS);
+    r.malformed = malformed;
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
     const bool check_points = !(P.skip_phases & 1u);
@@ -698,6 +715,7 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
         valid = (P.decoded_points ? !affine_is_identity(pu, pv) : point_on_curve_not_identity(pu, pv)) && valid;
         if ((P.own_test_mask >> k) & 1u) valid = is_torsion_free(pu, pv) && valid;
     }
+    r.valid = valid;
 
     // 3. challenge
     words8 c = u;
@@ -706,12 +724,12 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
         c = truncate250(digest);
     }
     if (P.c_out && write_c) store_words(P.c_out, item, c);
+    r.c = c;
 
-    // 4. equations (and the combined subgroup tests that ride on them)
-    bool eq_ok = true, proven = true;
+    // 4. half-size scalars (shared by both equations of the double scheme) and the combined subgroup tests
     const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
     half_scalars h{};
-    if (n_eq && P.eq[0].comb) {                             // shared by both equations of the double scheme
+    if (n_eq && P.eq[0].comb) {
         if (P.skip_phases & 8u) {                           // profiling only: stand-in scalars, no Euclid
 #pragma unroll
             for (int i = 0; i < 4; ++i) { h.a.w[i] = c.w[i] >> 2; h.b.w[i] = c.w[4 + i] >> 2; }
@@ -719,15 +737,50 @@ JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws,
             h = half_size_scalars(c);
         }
     }
-    for (uint32_t k = 0; k < n_eq; ++k) {
+    r.h = h;
+    bool proven = true;
+    for (uint32_t k = 0; k < n_eq; ++k)
         if (check_points && P.eq[k].comb) proven = combined_subgroup_test(P.eq[k], item, h) && proven;
-        eq_ok = check_equation(P.eq[k], item, ws, u, c, h) && eq_ok;
-    }
-    if (malformed) return ST_MALFORMED;
-    if (!valid) return ST_INVALID_POINT;
-    if (!check_points) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;
-    if (eq_ok && proven) return ST_OK;
+    r.proven = proven;
+    return r;
+}
+
+// ws = this lane's WS_WORDS_PER_LANE workspace words
+JJS_HD uint32_t finish_item(const verify_params& P, uint64_t item, uint32_t* ws, const prep_record& r) {
+    const words8 u = load_words(P.u, item);
+    bool eq_ok = true;
+    const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
+    for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, r.c, r.h) && eq_ok;
+    if (r.malformed) return ST_MALFORMED;
+    if (!r.valid) return ST_INVALID_POINT;
+    if (P.skip_phases & 1u) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;
+    if (eq_ok && r.proven) return ST_OK;
     return eq_ok ? ST_PENDING_EQ_HELD : ST_PENDING_EQ_FAILED;
+}
+
+JJS_HD uint32_t verify_item(const verify_params& P, uint64_t item, uint32_t* ws, bool write_c = true) {
+    return finish_item(P, item, ws, prepare_item(P, item, write_c));
+}
+
+// prep_record <-> the device buffer: c at prep + 32 i, (a, |b|) at prep + 32 n + 32 i, flags at prep + 64 n + i
+JJS_HD void store_prep(uint8_t* prep, uint64_t n, uint64_t i, const prep_record& r) {
+    store_words(prep, i, r.c);
+    words8 ab;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ab.w[k] = r.h.a.w[k]; ab.w[4 + k] = r.h.b.w[k]; }
+    store_words(prep + 32 * n, i, ab);
+    prep[64 * n + i] = (uint8_t)((r.malformed ? 1 : 0) | (r.valid ? 2 : 0) | (r.proven ? 4 : 0) | (r.h.b_neg ? 8 : 0));
+}
+JJS_HD prep_record load_prep(const uint8_t* prep, uint64_t n, uint64_t i) {
+    prep_record r;
+    const fe_src cs{prep, 32, 0}, abs_{prep + 32 * n, 32, 0};
+    r.c = load_words(cs, i);
+    const words8 ab = load_words(abs_, i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.h.a.w[k] = ab.w[k]; r.h.b.w[k] = ab.w[4 + k]; }
+    const uint8_t f = prep[64 * n + i];
+    r.malformed = (f & 1) != 0; r.valid = (f & 2) != 0; r.proven = (f & 4) != 0; r.h.b_neg = (f & 8) != 0;
+    return r;
 }
 
 // Resolve pass for an item the first pass left pending: every point that has not had its own subgroup

@@ -5,7 +5,7 @@
 <trace_dir>: output of  rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
 <pmc_dir>s : outputs of rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py ...   (one pass per
              counter group, as MI355X_MICROARCH.md prescribes)
-One batch = one verify_kernel launch followed by one resolve_kernel launch; counters are summed over the two
+One batch = prepare_kernel, verify_kernel and resolve_kernel, one launch each; counters are summed over the three
 and averaged over the batches of the run.  HBM bytes = FETCH_SIZE (KB) x 2 (gfx950 correction for 16 B/lane
 loads) + WRITE_SIZE (KB).
 """
@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-KERNELS = ("verify_kernel", "resolve_kernel")
+KERNELS = ("prepare_kernel", "verify_kernel", "resolve_kernel")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# VALU wave-instructions per 64 verifications (verify_kernel + resolve_kernel), from one PMC pass: the
+# VALU wave-instructions per 64 verifications (prepare + verify + resolve kernels), from one PMC pass: the
 # deterministic way to compare kernel variants (time = count x ~4.4 cycles; boxes differ by ~2 % in clock).
 # Usage (through gpurun): bash scripts/count_valu.sh [scheme] [path/to/variant.so]
 S=${1:-single}; LIB=${2:-}
@@ -11,7 +11,7 @@ import csv, glob, sys
 tot = {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        for k in ("verify_kernel", "resolve_kernel"):
+        for k in ("prepare_kernel", "verify_kernel", "resolve_kernel"):
             if k + "(" in r["Kernel_Name"]:
                 tot.setdefault(k, []).append(float(r["Counter_Value"]))
 s = sum(sum(v) / len(v) for v in tot.values())
