@@ -1,9 +1,11 @@
 // libjjs_gpu.so: HIP kernels (gfx950) + the C ABI of include/jjs_gpu.h.
 //
-// One signature per lane.  A launch is one persistent pass: the grid is sized to what the chip
-// can hold resident (256 CUs x blocks/CU from the occupancy query), each lane strides over the
-// batch, and each lane owns WS_WORDS_PER_LANE words of workspace for its window tables.  The
-// per-status tally is reduced with wave ballots and one atomic per wave per status.
+// One signature per lane.  A batch is three launches: prepare_kernel (hash, scalar lattice, pairing
+// tests; four waves per SIMD), verify_kernel (the equations; a persistent pass whose grid is what the chip
+// can hold resident -- 256 CUs x blocks/CU from the occupancy query -- each lane striding over the batch
+// and owning WS_WORDS_PER_LANE words of workspace for its window tables) and resolve_kernel (the items
+// verify_kernel could not decide).  The per-status tally is reduced with wave ballots and one atomic per
+// wave per status.  One process can drive several devices (jjs_init); all state is per device.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>

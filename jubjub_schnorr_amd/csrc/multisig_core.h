@@ -7,7 +7,7 @@
 //   combine                  src/multisig.rs:326-360  (u = sum z_i, R = RSa)
 //   aggregate_pk             src/multisig.rs:154-156
 // Like the reference these functions do not validate the points (they take JubJubExtended values);
-// only the encodings are checked (status 3).  Five passes, each one lane per participant or per
+// only the encodings are checked (status 3).  Six passes, each one lane per participant or per
 // transcript; the hash chains (2 + 2n and 3 + 4n inputs) run inside a lane.
 #pragma once
 #include "sign_core.h"
