@@ -62,7 +62,7 @@ JJS_HD ext_pt ext_double(const ext_pt& p, bool need_t) {
     fe_n xx = fq_sqr_hot(p.x);
     fe_n yy = fq_sqr_hot(p.y);
     auto c2 = fq_dbl(fq_sqr_hot(p.z));             // 2Z^2            <2,4>
-    auto g = fq_add(yy, xx);                   // Y^2 + X^2       <2,4>
+    auto g = fq_norm(fq_add(yy, xx));          // Y^2 + X^2       <1,4>: normalised so that g*h and g*e fit the product
     auto h = fq_sub(yy, xx);                   // Y^2 - X^2       <3,5>: used in products only, no carry pass
     auto f = fq_norm(fq_sub(fq_add(c2, xx), yy));   // 2Z^2 - (Y^2 - X^2) = (2Z^2 + X^2) - Y^2   <1,9>
     ext_pt r;
@@ -85,7 +85,7 @@ JJS_HD ext_pt ext_add_niels(const ext_pt& p, const niels_pt& n, bool neg, bool n
     auto e = fq_sub(b, a);                         // <3,5>
     auto f = fq_norm(fq_sub(d, c));                // <1,7>
     auto g = fq_add(d, c);                         // <3,6>
-    auto h = fq_add(b, a);                         // <2,4>
+    auto h = fq_norm(fq_add(b, a));                // <1,4>: normalised for g*h and h*e
     ext_pt r;
     r.x = fq_mul_hot(e, f);                    // same ordering rule as in ext_double
     r.z = fq_mul_hot(f, g);
@@ -103,7 +103,7 @@ JJS_HD ext_pt ext_add_affine_niels(const ext_pt& p, const fe_t& n_ypx, const fe_
     auto e = fq_sub(b, a);
     auto f = fq_norm(fq_sub(d, c));
     auto g = fq_add(d, c);
-    auto h = fq_add(b, a);
+    auto h = fq_norm(fq_add(b, a));
     ext_pt r;
     r.x = fq_mul_hot(e, f);
     r.z = fq_mul_hot(f, g);

@@ -176,62 +176,79 @@ JJS_HD fe<L, A> fq_select(bool c, const fe<L, A>& a, const fe<L, A>& b) {  // c 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Montgomery product (a*b + M*q) / 2^261, column by column.  -q^-1 = -1 mod 2^29 and q0 = 1, so the
-// quotient digit is m_k = -acc mod 2^29 and adding m_k*q0 just rounds the column up.
+// Montgomery product (a*b - M*q) / 2^261, column by column, in a SIGNED 64-bit accumulator.
+// q = 1 (mod 2^29), so the digit that clears column k is simply m_k = acc mod 2^29 when m_k*q is
+// SUBTRACTED: acc - m_k has its low 29 bits clear and the carry is the arithmetic shift acc >> 29 -- one mask
+// and one shift per column (adding m_k*q instead needs m_k = -acc mod 2^29: a negation, and a rounding add).
+// Subtracting in all nine columns could leave the result negative (down to -q), so the LAST digit goes the
+// other way: m_8 = 2^29 - (acc mod 2^29), in [1, 2^29], and m_8*q is added.  Then
+//     result = (a*b - sum_{k<8} m_k q 2^(29k) + m_8 q 2^232) / 2^261   lies in (0, a*b/2^261 + q],
+// the same range as the all-additive form, so the value bounds of fe<L, A> are unchanged.  The signed
+// accumulator holds at most 9 products of two limbs on the positive side and 8 digit products (< 2^58 each)
+// on the negative side: La*Lb*9*2^58 + carry < 2^63 needs La*Lb <= 3 (squares: L = 1).
 // ---------------------------------------------------------------------------------------------
-// low column epilogue: m = -acc mod 2^29 makes acc + m*q0 (q0 = 1) divisible by 2^29; the carry into the
-// next column is (acc + m) >> 29 = (acc + (2^29 - 1)) >> 29
-JJS_HD uint32_t mont_digit(uint64_t& acc) {
-    const uint32_t m = (0u - (uint32_t)acc) & MASK29;
-    acc = (acc + MASK29) >> 29;
-    return m;
+JJS_HD int64_t mont_ashr29(int64_t v) {   // floor(v / 2^29), also for negative v
+    return v >> 29;
 }
 
 JJS_HD raw9 mont_mul_body(const uint32_t* a, const uint32_t* b) {
-    uint32_t m[9];
+    int64_t m[9];
     raw9 r;
-    uint64_t acc = 0;
+    int64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)a[i] * b[k - i];
+        for (int i = 0; i <= k; ++i) acc += (int64_t)((uint64_t)a[i] * b[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * q29(k - i);
-        m[k] = mont_digit(acc);
+        for (int i = 0; i < k; ++i) acc -= m[i] * (int64_t)q29(k - i);
+        if (k < 8) {
+            m[k] = acc & (int64_t)MASK29;
+            acc = mont_ashr29(acc);                       // (acc - m_k) / 2^29
+        } else {
+            m[8] = (acc & (int64_t)MASK29) - ((int64_t)1 << 29);   // minus the digit: -m_8 in [-2^29, -1]
+            acc = mont_ashr29(acc - m[8]);                // (acc + m_8) / 2^29
+        }
     }
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a[i] * b[k - i];
+        for (int i = k - 8; i < 9; ++i) acc += (int64_t)((uint64_t)a[i] * b[k - i]);
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * q29(k - i);
-        r.l[k - 9] = (uint32_t)acc & MASK29;
-        acc >>= 29;
+        for (int i = k - 8; i < 9; ++i) acc -= m[i] * (int64_t)q29(k - i);   // i = 8: minus a negative digit
+        r.l[k - 9] = (uint32_t)(acc & (int64_t)MASK29);
+        acc = mont_ashr29(acc);
     }
     r.l[8] = (uint32_t)acc;
     return r;
 }
 // square: the 36 off-diagonal products are taken once against a doubled operand
 JJS_HD raw9 mont_sqr_body(const uint32_t* a) {
-    uint32_t m[9], a2[9];
+    int64_t m[9];
+    uint32_t a2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
     raw9 r;
-    uint64_t acc = 0;
+    int64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 17; ++k) {
 #pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; ++i) acc += (uint64_t)a[i] * a2[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
+        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; ++i) acc += (int64_t)((uint64_t)a[i] * a2[k - i]);
+        if ((k & 1) == 0) acc += (int64_t)((uint64_t)a[k / 2] * a[k / 2]);
         if (k < 9) {
 #pragma unroll
-            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * q29(k - i);
-            m[k] = mont_digit(acc);
+            for (int i = 0; i < k; ++i) acc -= m[i] * (int64_t)q29(k - i);
+            if (k < 8) {
+                m[k] = acc & (int64_t)MASK29;
+                acc = mont_ashr29(acc);
+            } else {
+                m[8] = (acc & (int64_t)MASK29) - ((int64_t)1 << 29);
+                acc = mont_ashr29(acc - m[8]);
+            }
         } else {
 #pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * q29(k - i);
-            r.l[k - 9] = (uint32_t)acc & MASK29;
-            acc >>= 29;
+            for (int i = k - 8; i < 9; ++i) acc -= m[i] * (int64_t)q29(k - i);
+            r.l[k - 9] = (uint32_t)(acc & (int64_t)MASK29);
+            acc = mont_ashr29(acc);
         }
     }
     r.l[8] = (uint32_t)acc;
@@ -311,7 +328,7 @@ JJS_HD raw9 mont_sqr_inl(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uin
 }
 template <int La, int Aa, int Lb, int Ab>
 JJS_HD fe_n fq_mul_hot(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
-    static_assert(La * Lb <= 6 && Aa * Ab <= 70, "see fq_mul");
+    static_assert(La * Lb <= 3 && Aa * Ab <= 70, "see fq_mul");
 #if defined(JJS_INLINE_HOT_MUL)
     raw9 r = mont_mul_inl(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8],
                           b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8]);
@@ -326,7 +343,7 @@ JJS_HD fe_n fq_mul_hot(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
 }
 template <int La, int Aa>
 JJS_HD fe_n fq_sqr_hot(const fe<La, Aa>& a) {
-    static_assert(La * La <= 6 && Aa * Aa <= 70, "see fq_sqr");
+    static_assert(La == 1 && Aa * Aa <= 70, "see fq_sqr");
 #if defined(JJS_INLINE_HOT_MUL)
     raw9 r = mont_sqr_inl(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8]);
 #else
@@ -340,7 +357,7 @@ JJS_HD fe_n fq_sqr_hot(const fe<La, Aa>& a) {
 
 template <int La, int Aa, int Lb, int Ab>
 JJS_HD fe_n fq_mul(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
-    static_assert(La * Lb <= 6, "product columns would overflow 64 bits: normalise an operand");
+    static_assert(La * Lb <= 3, "product columns would overflow the signed 64-bit accumulator: normalise an operand");
     static_assert(Aa * Ab <= 70, "product would not reduce below 2q: reduce an operand");
     raw9 r = mont_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8],
                            b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8]);
@@ -351,7 +368,7 @@ JJS_HD fe_n fq_mul(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
 }
 template <int La, int Aa>
 JJS_HD fe_n fq_sqr(const fe<La, Aa>& a) {
-    static_assert(La * La <= 6, "square columns would overflow 64 bits: normalise the operand");
+    static_assert(La == 1, "square columns would overflow the signed 64-bit accumulator: normalise the operand");
     static_assert(Aa * Aa <= 70, "square would not reduce below 2q");
     raw9 r = mont_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8]);
     fe_n o;
@@ -452,8 +469,8 @@ template <int L, int A>
 JJS_HD fe_c fq_canon_limbs(const fe<L, A>& a) {
     fe_c one = fq_zero();
     one.l[0] = 1;
-    fe_n y = fq_mul(a, one);  // (a + M q) / R' <= q since a < R'
-    // y in [0, q]: subtract q when y == q
+    fe_n y = fq_mul(fq_norm(a), one);  // (a - M q) / R' with M in (-R', R'): in [1, q] since a < R'
+    // y in [1, q]: q stands for zero
     bool is_q = true;
 #pragma unroll
     for (int i = 0; i < 9; ++i) is_q = is_q && (y.l[i] == q29(i));

@@ -56,12 +56,12 @@ JJS_HD void hades_permute(hades_state& st) {
         if (r < 4 || r >= 64) {
             const int fr = r < 4 ? r : r - 60;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i])));
+            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i]))));
         } else {
             const int k = r - 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
-            t[4] = fq_mul(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k]))), fe_from_const<1, 1>(JJS_HS_MU[k]));
+            t[4] = fq_mul(sbox5(fq_norm(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k])))), fe_from_const<1, 1>(JJS_HS_MU[k]));
         }
         hades_matrix(st, t);
     }

@@ -31,11 +31,11 @@ __host__ __device__ inline void one_round(hades_state& st, int rnd) {
     const bool full = (rnd < 4) || (rnd >= 64);
     fe<1, 3> t[5];
     if (full) {
-        for (int i = 0; i < 4; ++i) t[i] = fq_as<1, 3>(sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i]))));
+        for (int i = 0; i < 4; ++i) t[i] = fq_as<1, 3>(sbox5(fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i])))));
     } else {
         for (int i = 0; i < 4; ++i) t[i] = fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_RC[5 * rnd + i])));
     }
-    t[4] = fq_as<1, 3>(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_RC[5 * rnd + 4]))));
+    t[4] = fq_as<1, 3>(sbox5(fq_norm(fq_add(st.s[4], fe_from_const<1, 1>(JJS_RC[5 * rnd + 4])))));
     for (int i = 0; i < 5; ++i) st.s[i] = fq_dot_const<5, 3>(JJS_MDS[i], t);
 }
 
@@ -48,7 +48,7 @@ __host__ __device__ inline void run_stage(int stage, const uint32_t* in, uint32_
     for (int i = 0; i < OUT_WORDS; ++i) out[i] = 0;
     switch (stage) {
     case S_MUL: { fe_n r = fq_mul(a, b); put(out, pos, r.l, 9); break; }
-    case S_SQR: { fe_n r = fq_sqr(a); put(out, pos, r.l, 9); fe_n r2 = fq_sqr(fq_add(a, b)); put(out, pos, r2.l, 9); break; }
+    case S_SQR: { fe_n r = fq_sqr(a); put(out, pos, r.l, 9); fe_n r2 = fq_sqr(fq_norm(fq_add(a, b))); put(out, pos, r2.l, 9); break; }
     case S_ADDSUB: {
         auto s = fq_norm(fq_add(a, b)); put(out, pos, s.l, 9);
         auto t = fq_norm(fq_sub(a, b)); put(out, pos, t.l, 9);
@@ -60,7 +60,7 @@ __host__ __device__ inline void run_stage(int stage, const uint32_t* in, uint32_
         fe<1, 3> t[5] = {fq_as<1, 3>(a), fq_as<1, 3>(b), fq_as<1, 3>(c), fq_as<1, 3>(d), fq_as<1, 3>(e)};
         for (int i = 0; i < 5; ++i) { fe_n r = fq_dot_const<5, 3>(JJS_MDS[i], t); put(out, pos, r.l, 9); }
         break; }
-    case S_SBOX: { fe_n r = sbox5(fq_add(a, fe_from_const<1, 1>(JJS_RC[7]))); put(out, pos, r.l, 9); break; }
+    case S_SBOX: { fe_n r = sbox5(fq_norm(fq_add(a, fe_from_const<1, 1>(JJS_RC[7])))); put(out, pos, r.l, 9); break; }
     case S_ROUND_FULL: case S_ROUND_PARTIAL: {
         hades_state st; st.s[0] = a; st.s[1] = b; st.s[2] = c; st.s[3] = d; st.s[4] = e;
         one_round(st, stage == S_ROUND_FULL ? 1 : 10);

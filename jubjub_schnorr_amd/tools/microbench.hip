@@ -13,10 +13,11 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 enum Op { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, ADD_U32, LSHL_ADD_U64, ADDC_U32,
-          MUL_F64, MAD_U64_U32_SGPR, ADD3_U32, N_OPS };
+          MUL_F64, MAD_U64_U32_SGPR, ADD3_U32, MAD_I64_I32, ASHR_I64, LSHR_B64, AND_B32, ALIGNBIT_B32, N_OPS };
 static const char* kNames[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
                                "v_fma_f64", "v_add_u32", "v_lshl_add_u64", "v_addc_co_u32", "v_mul_f64",
-                               "v_mad_u64_u32(sgpr b)", "v_add3_u32"};
+                               "v_mad_u64_u32(sgpr b)", "v_add3_u32", "v_mad_i64_i32(sgpr b)", "v_ashrrev_i64", "v_lshrrev_b64",
+                               "v_and_b32", "v_alignbit_b32"};
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -77,6 +78,26 @@ __global__ __launch_bounds__(256) void ubench(uint64_t* out, int iters, uint32_t
 #define X(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(bb));
                 REP8(X)
 #undef X
+            } else if constexpr (OP == MAD_I64_I32) {
+#define X(i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "s"(sb) : "vcc");
+                REP8(X)
+#undef X
+            } else if constexpr (OP == ASHR_I64) {
+#define X(i) asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(acc[i]));
+                REP8(X)
+#undef X
+            } else if constexpr (OP == LSHR_B64) {
+#define X(i) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[i]));
+                REP8(X)
+#undef X
+            } else if constexpr (OP == AND_B32) {
+#define X(i) { uint32_t t = (uint32_t)acc[i]; asm volatile("v_and_b32 %0, %1, %0" : "+v"(t) : "v"(b)); acc[i] = t; }
+                REP8(X)
+#undef X
+            } else if constexpr (OP == ALIGNBIT_B32) {
+#define X(i) { uint32_t t = (uint32_t)acc[i]; asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(t) : "v"(b)); acc[i] = t; }
+                REP8(X)
+#undef X
             } else if constexpr (OP == ADDC_U32) {
 #define X(i) { uint32_t t = (uint32_t)acc[i]; asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(t) : "v"(b) : "vcc"); acc[i] = t; }
                 REP8(X)
@@ -133,6 +154,11 @@ int main() {
         if (run<ADD3_U32>(dout, w, iters)) return 1;
         if (run<LSHL_ADD_U64>(dout, w, iters)) return 1;
         if (run<ADDC_U32>(dout, w, iters)) return 1;
+        if (run<MAD_I64_I32>(dout, w, iters)) return 1;
+        if (run<ASHR_I64>(dout, w, iters)) return 1;
+        if (run<LSHR_B64>(dout, w, iters)) return 1;
+        if (run<AND_B32>(dout, w, iters)) return 1;
+        if (run<ALIGNBIT_B32>(dout, w, iters)) return 1;
     }
     CHECK(hipFree(dout));
     return 0;

@@ -237,18 +237,24 @@ def check_product(res, want_mod):
 
 
 def test_montgomery_product_at_the_edges_of_its_static_bounds():
-    """fq_mul demands La*Lb <= 6 and Aa*Ab <= 70; the result must be exact, < 2q, with normalised limbs."""
+    """fq_mul demands La*Lb <= 3 (signed 64-bit columns) and Aa*Ab <= 70; squares take normalised limbs.  The
+    result must be exact, in (0, 2q), with normalised limbs."""
     rng = np.random.default_rng(77)
     rinv = pow(RP, -1, o.Q)
-    for (la, aa), (lb, ab) in (((1, 2), (1, 2)), ((3, 5), (2, 4)), ((6, 7), (1, 10)), ((2, 35), (3, 2)), ((1, 70), (1, 1)), ((3, 8), (2, 8))):
-        assert la * lb <= 6 and aa * ab <= 70
+    for (la, aa), (lb, ab) in (((1, 2), (1, 2)), ((3, 5), (1, 4)), ((1, 7), (3, 10)), ((1, 35), (3, 2)), ((1, 70), (1, 1)),
+                               ((3, 8), (1, 8)), ((1, 1), (3, 70))):
+        assert la * lb <= 3 and aa * ab <= 70
         a, b = edge_limb_vectors(rng, 200, la, aa), edge_limb_vectors(rng, 200, lb, ab)
         res = hl.raw_mul(a, b)
         check_product(res, [limbs_val(a[i]) * limbs_val(b[i]) * rinv % o.Q for i in range(len(a))])
-    for la, aa in ((1, 2), (2, 4), (2, 8), (1, 8)):
-        assert la * la <= 6 and aa * aa <= 70
+        assert all(limbs_val(r) > 0 for r in res)          # the biased last digit keeps the result positive
+    zero = np.zeros((1, 9), np.uint32)
+    assert limbs_val(hl.raw_mul(zero, zero)[0]) == o.Q      # 0 * 0 comes out as q, never as a negative number
+    for la, aa in ((1, 2), (1, 4), (1, 8)):
+        assert aa * aa <= 70
         a = edge_limb_vectors(rng, 200, la, aa)
         check_product(hl.raw_sqr(a), [limbs_val(x) ** 2 * rinv % o.Q for x in a])
+    assert limbs_val(hl.raw_sqr(zero)[0]) == o.Q
 
 
 def test_dot_products_at_the_edges_of_their_static_bounds():
