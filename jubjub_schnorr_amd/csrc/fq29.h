@@ -256,14 +256,14 @@ JJS_HD raw9 mont_sqr_body(const uint32_t* a) {
 }
 
 // Out-of-line entry points: 18 scalar arguments travel in v0..v17, the result in v0..v8.  Keeping
-// the 240-instruction body out of line bounds the kernel's code size (instruction cache) at the
+// the ~190-instruction body out of line bounds the kernel's code size (instruction cache) at the
 // price of ~25 register moves per call.
 JJS_CALL raw9 mont_mul_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
                             uint32_t a6, uint32_t a7, uint32_t a8, uint32_t b0, uint32_t b1, uint32_t b2,
                             uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
-    // one hand-scheduled block (tools/gen_mont_asm.py): 153 v_mad_u64_u32 in a single accumulator chain +
-    // 52 shifts/masks; the result limb j overwrites a_j
+    // one hand-scheduled block (tools/gen_mont_asm.py): 153 multiply-adds in a single accumulator chain +
+    // 36 masks/shifts; the result limb j overwrites a_j
     asm(JJS_MONT_MUL_ASM
         : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
           [a7] "+v"(a7), [a8] "+v"(a8)
