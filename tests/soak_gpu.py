@@ -42,6 +42,20 @@ def main():
         print(f"{scheme}: {n} items, oracle {t_cpu:.0f} s, statuses {np.bincount(want, minlength=4).tolist()}, "
               f"tally {tally.cpu().numpy().tolist()}, mismatches {bad}", flush=True)
         assert bad == 0 and tally.cpu().numpy().tolist() == np.bincount(want, minlength=4).tolist()
+        # the same batch through the wire entry points: points compressed on the device, decoded again by the
+        # decoder; every point here is on the curve, so the statuses must be the same
+        dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+        comp = {k: eng.compress(dev[k]) for k in dev if dev[k].shape[1] == 64}
+        if scheme == "single":
+            sig, pk = torch.cat([dev["u"], comp["R"]], 1), comp["PK"]
+        elif scheme == "double":
+            sig, pk = torch.cat([dev["u"], comp["R"], comp["Rp"]], 1), torch.cat([comp["PK"], comp["PKp"]], 1)
+        else:
+            sig, pk = torch.cat([dev["u"], comp["R"]], 1), torch.cat([comp["PK"], comp["Gen"]], 1)
+        st_w, tally_w = eng.verify_wire(scheme, sig.contiguous(), pk.contiguous(), dev["m"])
+        bad_w = int((st_w.cpu().numpy() != want).sum())
+        print(f"{scheme}: wire entry point, mismatches {bad_w}", flush=True)
+        assert bad_w == 0 and tally_w.cpu().numpy().tolist() == tally.cpu().numpy().tolist()
     print("SOAK OK")
 
 
