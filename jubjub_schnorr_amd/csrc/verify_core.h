@@ -421,7 +421,7 @@ JJS_HD half_scalars half_size_scalars(const words8& c) {
             const int p = len0 - 52;                                   // >= 75: r0 >= r1 >= 2^126 in active lanes
             const double x = (double)(bits64_at(r0, len0 - 64) >> 12), y = (double)(bits64_at(r1, len0 - 64) >> 12);
             const int sh = 126 - p;
-            const double th = sh > 0 ? (double)(1ull << sh) : 1.0;     // sh <= 51
+            const double th = sh > 0 ? (double)(1ull << (sh > 62 ? 62 : sh)) : 1.0;   // sh <= 51 in active lanes
             const lehmer_run L = lehmer_steps(x, y, th, active);
             const bool odd = (L.steps & 1u) != 0;
             uint32_t A[8], B[8], n0[8], n1[8], m0[4], m1[4];
