@@ -15,6 +15,7 @@ from test_gpu_parity import to_wire  # noqa: E402
 
 
 def main(devices: int) -> None:
+    import torch
     import jubjub_schnorr_amd as jjs
     eng = jjs.Engine(devices)
     assert eng.device_count == devices, eng.device_count
@@ -40,8 +41,23 @@ def main(devices: int) -> None:
         want = oracle_verify(scheme, b)
         st, tally = eng.verify_wire(scheme, *to_wire(scheme, b))
         assert st.tolist() == want.tolist() and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    # blocks larger than one pipeline chunk (2^18 items) on every device: inputs from the device signer, every
+    # 7th message tampered, statuses known by construction
+    n = devices * (1 << 18) + 999
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    def scal(top):
+        t = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen)
+        t[:, 31] &= top
+        return t.cuda()
+    sk, rnd, m = scal(0x07), scal(0x07), scal(0x3F)
+    sk[:, 0] |= 1
+    u, R, PK = eng.sign("single", sk, rnd, m)
+    bad = (torch.arange(n, device="cuda") % 7) == 3
+    m[bad, 0] ^= 1
+    expect = (bad.to(torch.uint8) * 2).cpu().numpy()
+    st, tally = eng.verify("single", *[t.cpu().numpy() for t in (u, R, PK, m)])
+    assert (st == expect).all() and tally.tolist() == [int((expect == k).sum()) for k in range(4)]
     # the device-pointer calls still act on the current device
-    import torch
     b = make_batch("single", 300, seed=77)
     want = oracle_verify("single", b)
     st, _ = eng.verify("single", *[torch.from_numpy(b[k]).cuda() for k in ARG_ORDER["single"]])
