@@ -355,6 +355,20 @@ JJS_HD fe_n fq_sqr_hot(const fe<La, Aa>& a) {
     return o;
 }
 
+// Square of (normalised limbs + a Hades round constant) without the carry pass that the general rule La == 1
+// would demand: the constants are public, and tools/gen_constants.py checks at generation time that for every
+// one of them the 9-term column sums of this square stay below 28 * 2^58 (the accumulator holds 32 * 2^58).
+// Only hades29.h may call it.
+template <int Aa>
+JJS_HD fe_n fq_sqr_plus_const(const fe<2, Aa>& a) {
+    static_assert(Aa * Aa <= 70, "see fq_sqr");
+    raw9 r = mont_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8]);
+    fe_n o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = r.l[i];
+    return o;
+}
+
 template <int La, int Aa, int Lb, int Ab>
 JJS_HD fe_n fq_mul(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
     static_assert(La * Lb <= 3, "product columns would overflow the signed 64-bit accumulator: normalise an operand");

@@ -14,17 +14,13 @@ struct hades_state {
     fe_n s[5];
 };
 
-template <int L, int A>
-JJS_HD fe_n sbox5(const fe<L, A>& x) {
-#if defined(JJS_HOT_SBOX)
-    fe_n x2 = fq_sqr_hot(x);
-    fe_n x4 = fq_sqr_hot(x2);
-    return fq_mul_hot(x4, x);
-#else
-    fe_n x2 = fq_sqr(x);
+// x^5 for x = lane + round constant, taken as it comes out of the addition (limbs below 2^30): see
+// fq_sqr_plus_const for why the first square needs no carry pass; the last product takes L = 2 anyway.
+template <int A>
+JJS_HD fe_n sbox5(const fe<2, A>& x) {
+    fe_n x2 = fq_sqr_plus_const(x);
     fe_n x4 = fq_sqr(x2);
     return fq_mul(x4, x);
-#endif
 }
 
 // The linear layer: st.s[i] = (sum_j S[i][j] * t[j]) / 2^29 with S[i][j] = JJS_HS_HANKEL[i + j].  On the
@@ -56,12 +52,12 @@ JJS_HD void hades_permute(hades_state& st) {
         if (r < 4 || r >= 64) {
             const int fr = r < 4 ? r : r - 60;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_norm(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i]))));
+            for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i])));
         } else {
             const int k = r - 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
-            t[4] = fq_mul(sbox5(fq_norm(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k])))), fe_from_const<1, 1>(JJS_HS_MU[k]));
+            t[4] = fq_mul(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k]))), fe_from_const<1, 1>(JJS_HS_MU[k]));
         }
         hades_matrix(st, t);
     }

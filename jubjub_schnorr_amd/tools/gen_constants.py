@@ -32,6 +32,9 @@ def inv(a):
     return pow(a % Q, Q - 2, Q)
 
 
+MASK29 = (1 << 29) - 1
+
+
 def mont(x):
     return x % Q * MONT % Q
 
@@ -369,6 +372,17 @@ def main():
     for trial in range(3):
         st = [int.from_bytes(hashlib.sha256(b"hades-scaled-%d-%d" % (trial, i)).digest(), "little") % Q for i in range(WIDTH)]
         assert hades_reference(st) == hades_scaled_model(st, rc_full, kap, mu, lam_end), "scaled Hades differs"
+    # The S-box squares (state lane + round constant) WITHOUT a carry pass in between (fq_sqr_plus_const in
+    # fq29.h): the lane has normalised limbs (< 2^29, top limb of a value below 2q), the constant is one of the
+    # 100 below, and the 9-term column sums of that square must stay inside the signed 64-bit accumulator.
+    top_limb = (2 * Q - 1) >> 232
+    worst = 0
+    for c in [x for row in rc_full for x in row] + list(kap):
+        lim = [(mont(c) >> (29 * i)) & MASK29 for i in range(8)] + [mont(c) >> 232]
+        x = [MASK29 + lim[i] for i in range(8)] + [top_limb + lim[8]]
+        worst = max(worst, max(sum(x[i] * x[col - i] for i in range(max(0, col - 8), min(col, 8) + 1)) for col in range(17)))
+    assert worst < 28 << 58, "a Hades round constant would overflow the unnormalised S-box square"
+    L.append("// worst 9-term column of (lane + round constant)^2 over all round constants: %.1f * 2^58 (limit 32)" % (worst / 2 ** 58))
     L.append("// Hades with the small-integer matrix S = L / (i + j + 5), L = 360360 (scaled_hades_constants())")
     L.append("JJS_CONST uint32_t JJS_HS_MAT[5][5] = {" + ", ".join("{" + ", ".join(str(x) for x in row) + "}" for row in SMALL_S) + "};")
     assert all(SMALL_S[i][j] == SMALL_S[0][i + j] if i + j < 5 else SMALL_S[i][j] == SMALL_S[i + j - 4][4] for i in range(5) for j in range(5))
