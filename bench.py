@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark: Schnorr-on-JubJub batch verification throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme single|double|vargen]
-                    [--log2-items-per-gpu 20] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme all|single|double|vargen]
+                    [--log2-items-per-gpu L] [--no-cpu-baseline] [--wire]
 
 One "step" = one pass of the verify hot path over one batch of synthetic signatures that is
-already resident in HBM (BASELINE.json configs[1]: 2^20 single signatures on one MI355X).  For
-N > 1 the driver launches one process per GPU (torch.distributed.run); every rank verifies its own
-2^20-item shard and the only exchange is an RCCL all-reduce of the 4-counter tally, inside the
-timed region.  Rank 0 prints ONE JSON line.
+already resident in HBM.  The headline (`value`) is BASELINE.json configs[1]: 2^20 single signatures on
+one MI355X; the same invocation then times configs[2] (2^20 double) and configs[4] (2^20 var-generator)
+with the same protocol and reports them under `schemes`.  For N > 1 the driver launches one process per
+GPU (torch.distributed.run); every rank verifies its own shard -- 2^20 items per GPU at N = 2, 4 and
+2^21 per GPU at N = 8, which is configs[3] (2^24 single signatures over 8 GPUs) exactly -- and the only
+exchange is an RCCL all-reduce of the 4-counter tally, inside the timed region.  Rank 0 prints ONE JSON line.
 
 Synthetic inputs: seed 0x6a6a73, 4096 distinct keys, item i signed with key i mod
 4096 by the library's own GPU signer (tests pin it bit-exact to the oracle), then 15/16 valid,
@@ -102,10 +104,26 @@ def make_inputs(eng, scheme: str, n: int, rank: int):
     return {k: v.contiguous() for k, v in a.items()}, expect
 
 
+def host_info():
+    """CPU model, cores the box has and cores this process may run on (core count stated)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity_cores": affinity}
+
+
 def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budget_s: float = 12.0):
     """Oracle (C restatement of the reference's algorithm) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import jjs_oracle_c as oc
     try:
         oc.build(native=True)
@@ -113,7 +131,8 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
     except Exception:
         native = False
     fn = {"single": oc.verify_single, "double": oc.verify_double, "vargen": oc.verify_vargen}[scheme]
-    threads = max(1, min(16, os.cpu_count() or 1, oc.max_threads(native)))
+    info = host_info()
+    threads = max(1, min(info["affinity_cores"], oc.max_threads(native)))     # every core this process may use
     probe = 2048
     host = {k: arrays[k][:probe].cpu().numpy() for k in ARG_ORDER[scheme]}
     t0 = time.perf_counter()
@@ -136,44 +155,63 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
         _, c = fn(*[host[x][:k] for x in ARG_ORDER[scheme]], threads=threads, native=native, want_c=True)
         canonical = st[:k] != 3
         c_agree = bool((c[canonical] == gpu_challenge[:k].cpu().numpy()[canonical]).all())
-    return {"value": n / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "verifications/s", "cores": threads, "threads_used": threads, "kind": "port",
+            "cpu_model": info["cpu_model"], "nproc": info["nproc"], "affinity_cores": info["affinity_cores"],
             "sample": f"first {n} items of the same {scheme} batch, oracle/jjs_oracle.c "
-                      f"({'-march=native' if native else 'generic x86-64'}), {dt:.1f} s",
-            "one_thread": {"value": one_thread, "items": k1},
+                      f"({'-march=native' if native else 'generic x86-64'}, OpenMP, {threads} threads), {dt:.1f} s",
+            "one_thread": {"value": one_thread, "items": k1, "config": "BASELINE.json configs[0]: 1 024 signatures, CPU only"},
             "statuses_equal_gpu": agree, "challenges_equal_gpu_on_2^16_sample": c_agree}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scheme", default="single", choices=["single", "double", "vargen"])
-    ap.add_argument("--log2-items-per-gpu", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--wire", action="store_true",
-                    help="feed the reference's wire formats (compressed points, decoded on the device)")
-    args = ap.parse_args()
+def csrc_hash() -> str:
+    """SHA-256 over the kernel sources: ties a committed PMC profile to the code it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "jubjub_schnorr_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
+
+def committed_pmc(scheme: str, n: int):
+    """Counters of the committed PMC pass for this scheme, or None when there is none for the code that is running
+    (profiles/pmc_latest.json carries the csrc hash it was measured on)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("csrc_sha256") != csrc_hash():
+        return None
+    rec = rec.get("schemes", {}).get(scheme)
+    if not rec or rec.get("items") != n:
+        return None
+    return rec
+
+
+def items_per_gpu(scheme: str, world: int, override) -> int:
+    """BASELINE.json: configs[1]/[2]/[4] = 2^20 items on one GPU; configs[3] = 2^24 single signatures over 8 GPUs,
+    i.e. 2^21 per GPU.  N = 1, 2, 4 keep 2^20 per GPU so that the N = 1 point of a scaling run equals the headline."""
+    if override is not None:
+        return 1 << override
+    return 1 << 21 if (scheme == "single" and world == 8) else 1 << 20
+
+
+def workload_name(scheme: str, n: int, world: int) -> str:
+    if scheme == "single" and world == 8 and n == 1 << 21:
+        return "2^24 single signatures sharded over 8 GPUs, 2^21 per GPU, resident in HBM (BASELINE.json configs[3])"
+    cfg = {"single": 1, "double": 2, "vargen": 4}[scheme]
+    lg = n.bit_length() - 1
+    exact = " " if (n == 1 << 20) else " (size override) "
+    return f"2^{lg} {scheme} signatures per GPU, resident in HBM{exact}(BASELINE.json configs[{cfg}] per GPU)"
+
+
+def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with_cpu: bool):
+    """W warm-up steps, then exactly K timed steps between two barrier + synchronize fences; returns the record of
+    this scheme (rank 0) and whether every bit-exact check held (every rank)."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import jubjub_schnorr_amd as jjs
     from jubjub_schnorr_amd.sharding import allreduce_tally
-    eng = jjs.engine()
-    scheme = args.scheme
-    n = 1 << args.log2_items_per_gpu
     arrays, expect = make_inputs(eng, scheme, n, rank)
     call = [arrays[k] for k in ARG_ORDER[scheme]]
     if args.wire:
@@ -191,22 +229,19 @@ def main():
     def run_verify():
         return eng.verify_wire(scheme, *wire) if args.wire else eng.verify(scheme, *call)
 
-    def step():
-        st, tally = run_verify()
-        allreduce_tally(tally)              # RCCL over xGMI: 4 x int64, the path's only exchange
-        return st, tally
-
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        st, tally = step()
+        st, tally = run_verify()
+        allreduce_tally(tally)              # RCCL over xGMI: 4 x int64, the path's only exchange
     fence()
     evs = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        # HIP events on the stream the kernels are launched on (the engine enqueues on torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         st, tally_local = run_verify()
@@ -230,63 +265,127 @@ def main():
     if dist is not None:
         dist.all_reduce(total_expected)
     ok_global = bool(torch.equal(tally.cpu(), total_expected.cpu()))
+    ok = ok_status and ok_tally and ok_global
+    if rank != 0:
+        return None, ok
+
+    algo_bytes = WIRE_BYTES[scheme] if args.wire else ALGO_BYTES[scheme]
+    achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
+    traffic, alu = None, None
+    pmc = None if args.wire else committed_pmc(scheme, n)
+    if pmc:
+        traffic = pmc.get("hbm_bytes_per_launch")
+        # the binding roofline: VALU issue.  Instruction count per launch from the committed PMC pass
+        # of THIS code (hash-checked), rate from THIS run's kernel time; ceiling = 1024 SIMDs issuing one
+        # wave-instruction every 4.2 cycles (microbenchmarked cost of the cheapest multiply) at 2.4 GHz nominal
+        insts = pmc.get("valu_wave_instr_per_launch")
+        if insts:
+            rate = insts / (kernel_ms * 1e-3)
+            peak = 1024 * 2.4e9 / 4.2
+            alu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instr/s", "frac": rate / peak,
+                   "valu_wave_instr_per_64_verifies": insts / (n / 64), "source": pmc.get("source")}
+    rec = {
+        "value": n * world * args.steps / elapsed,
+        "unit": "verifications/s",
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "workload": workload_name(scheme, n, world),
+        "items_per_gpu": n,
+        "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes * n,
+                     "kernel": ("decode_kernel + " if args.wire else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
+                     "kernel_ms": kernel_ms,
+                     "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6; "
+                             "traffic / alu_roofline are null unless profiles/pmc_latest.json was measured on this csrc hash"},
+        "alu_roofline": alu,
+    }
+    if with_cpu:
+        gpu_c = eng.challenge(scheme, *[arrays[k][: 1 << 16] for k in ARG_ORDER[scheme][1:]])
+        rec["cpu_baseline"] = cpu_baseline(scheme, arrays, st, gpu_c)
+    return rec, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scheme", default="all", choices=["all", "single", "double", "vargen"],
+                    help="all (default): headline = single, plus double and vargen in `schemes`")
+    ap.add_argument("--log2-items-per-gpu", type=int, default=None,
+                    help="override the BASELINE sizes (2^20 per GPU; 2^21 for single at --gpus 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wire", action="store_true",
+                    help="feed the reference's wire formats (compressed points, decoded on the device)")
+    ap.add_argument("--lib", default=None, help="another in-tree build of the engine (A/B timing of kernel variants)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run, one rank per GPU")
+    torch.cuda.set_device(local_rank)         # before any other GPU call of this process
+    dist = None
+    backend = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
+        assert dist.get_world_size() == args.gpus and backend == "nccl", (dist.get_world_size(), backend)
+
+    if args.lib:
+        from jubjub_schnorr_amd import _ffi
+        _ffi.select_library(args.lib)
+    import jubjub_schnorr_amd as jjs
+    eng = jjs.engine()
+    schemes = ["single", "double", "vargen"] if args.scheme == "all" else [args.scheme]
+    with_cpu = (not args.no_cpu_baseline) and world == 1
+    records, all_ok = {}, True
+    for scheme in schemes:
+        n = items_per_gpu(scheme, world, args.log2_items_per_gpu)
+        rec, ok = run_scheme(eng, scheme, n, args, dist, rank, world, with_cpu)
+        records[scheme] = rec
+        all_ok = all_ok and ok
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        total_items = n * world * args.steps
-        value = total_items / elapsed
-        algo_bytes = WIRE_BYTES[scheme] if args.wire else ALGO_BYTES[scheme]
-        achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
-        traffic, alu = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("scheme") == scheme and rec.get("items") == n:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    # the binding roofline: VALU issue.  Instruction count per launch from the
-                    # committed PMC pass, rate from THIS run's kernel time; ceiling = 1024 SIMDs issuing one
-                    # wave-instruction every 4.2 cycles (microbenchmarked cost of the cheapest multiply) at 2.4 GHz
-                    insts = rec.get("valu_wave_instr_per_launch")
-                    if insts:
-                        rate = insts / (kernel_ms * 1e-3)
-                        peak = 1024 * 2.4e9 / 4.2
-                        alu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instr/s",
-                               "frac": rate / peak, "source": rec.get("source")}
-            except Exception:
-                traffic, alu = None, None
+        head = records[schemes[0]]
         out = {
             "metric": "Schnorr verifications/sec",
-            "value": value,
+            "value": head["value"],
             "unit": "verifications/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (29-bit), u64 accumulators",
             "data": "synthetic",
-            "config": {"workload": f"2^{args.log2_items_per_gpu} {scheme} signatures per GPU, resident in HBM "
-                                   f"(BASELINE.json configs[{ {'single': 1, 'double': 2, 'vargen': 4}[scheme] }])",
-                       "scheme": scheme, "items_per_gpu": n, "input_format": "wire (compressed points)" if args.wire else "affine", "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
+            "config": {"workload": head["workload"], "scheme": schemes[0], "items_per_gpu": head["items_per_gpu"],
+                       "global_items": head["items_per_gpu"] * world,
+                       "input_format": "wire (compressed points)" if args.wire else "affine",
+                       "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
+                       "distributed": {"backend": backend, "world_size": world},
                        "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points"},
-            "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("decode_kernel + " if args.wire else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
-                         "kernel_ms": kernel_ms,
-                         "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6"},
-            "alu_roofline": alu,
+            "bit_exact": head["bit_exact"],
+            "roofline": head["roofline"],
+            "alu_roofline": head["alu_roofline"],
         }
-        if not args.no_cpu_baseline:
-            gpu_c = eng.challenge(scheme, *[arrays[k][: 1 << 16] for k in ARG_ORDER[scheme][1:]])
-            out["cpu_baseline"] = cpu_baseline(scheme, arrays, st, gpu_c)
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if len(schemes) > 1:        # BASELINE.json metric: "single + double" (and configs[4], the per-item generator)
+            out["schemes"] = {s: records[s] for s in schemes[1:]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if not (ok_status and ok_tally and ok_global):
+    if not all_ok:
         raise SystemExit("bit-exact check failed")
 
 

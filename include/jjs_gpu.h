@@ -29,15 +29,20 @@
  *
  * Return value: 0 = success; negative = engine error, in which case outputs are unspecified:
  *   -1 bad argument, -2 HIP error, -3 collective (RCCL) error, -4 not initialised.
- * No exceptions, no aborts.  jjs_last_error() describes the last failure of the calling process.
+ * No exceptions, no aborts.  jjs_last_error() describes the last failure of the calling THREAD (the
+ * buffer is thread-local: the pointer stays valid and is only rewritten by later failures of the same thread).
  *
  * Ownership: the caller owns every buffer passed in; the library keeps nothing after a blocking
  * call returns (after the stream has drained, for the *_dev calls).  The library owns its device
  * tables, workspaces, streams and RCCL communicators between jjs_init and jjs_shutdown.
  *
+ * There are no switches, environment variables or hidden entry points that turn a check off: the profiling
+ * ablations and the logical-device test mode live in a separate build (libjjs_gpu_prof.so, -DJJS_PROFILING,
+ * include/jjs_gpu_profiling.h) that the product never loads.
+ *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
- * thread and are serialised by one internal mutex.  The *_dev calls are asynchronous, but because they
- * share the engine's workspaces the library orders them on the device (each launch waits for the
+ * thread and are serialised by one internal mutex (jjs_stream_sync only reads state under it and waits
+ * outside).  The *_dev calls are asynchronous, but because they share the engine's workspaces the library orders them on the device (each launch waits for the
  * previous one on the same device, also across streams): one batch in flight per device.
  */
 #ifndef JJS_GPU_H
@@ -169,9 +174,11 @@ int jjs_debug_poseidon_dev(const void* in, size_t k, size_t n, void* out, void* 
 /* out[i] bit0 = on curve, bit1 = torsion free (pairing test, as used by verify; identity counts as
  * torsion free), bit2 = identity, bit3 = torsion free by the reference's definition [r]P == O */
 int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* stream);
-/* profiling ablations ONLY (results become meaningless): skip phases of the verify kernel in later
- * launches; bit0 = point validity, bit1 = challenge hash, bit2 = equations; 0 restores production. */
-int jjs_debug_skip_phases(unsigned mask);
+/* The half-size scalars the verify kernels derive from a challenge (csrc/verify_core.h half_size_scalars, the
+ * device code path): for c[i] (n x 32 bytes, canonical, < r) a_out[i], b_out[i] (n x 16 bytes each, little-endian)
+ * and b_neg_out[i] (n bytes) with a = +-b*c (mod r), a, |b| < 2^126: Euclid's algorithm on (r, c) stopped at the
+ * first remainder below 2^126.  Device pointers, 16-byte aligned. */
+int jjs_debug_half_scalars_dev(const void* c, size_t n, void* a_out, void* b_out, void* b_neg_out, void* stream);
 /* copies the fixed-base table of G (which = 0) or G' (which = 1) to host memory; size in bytes via
  * jjs_debug_comb_table_bytes() */
 size_t jjs_debug_comb_table_bytes(void);

@@ -1,0 +1,27 @@
+/*
+ * Extra entry points of the PROFILING build of the engine (jubjub_schnorr_amd/libjjs_gpu_prof.so, compiled from
+ * the same sources with -DJJS_PROFILING).  They switch verification work off or let several logical devices share
+ * one card, so they are compiled OUT of the product library libjjs_gpu.so (tests/test_abi.py checks that the
+ * symbols are absent there).  Used only by jubjub_schnorr_amd/tools/phase_profile.py and tests/multidevice_child.py.
+ */
+#ifndef JJS_GPU_PROFILING_H
+#define JJS_GPU_PROFILING_H
+
+#include "jjs_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Ablations (results become meaningless): skip phases of the verify kernels in later launches; bit0 = point
+ * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars); 0 restores the full path. */
+int jjs_debug_skip_phases(unsigned mask);
+/* Test mode for boxes with one GPU: a later jjs_init(k) with k above the visible device count creates k logical
+ * devices (own stream, tables, workspace, staging each) that share the visible cards round-robin; the tallies are
+ * then summed on the host, since two ranks on one card cannot form an RCCL clique. */
+int jjs_debug_allow_virtual_devices(int allow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JJS_GPU_PROFILING_H */

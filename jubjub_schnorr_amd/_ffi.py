@@ -8,8 +8,11 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# JJS_GPU_LIB: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
-LIB_PATH = os.environ.get("JJS_GPU_LIB") or os.path.join(HERE, "libjjs_gpu.so")
+# The product library.  No environment variable can redirect the loader; tools that need another in-tree build
+# of the same sources (the -DJJS_PROFILING build, A/B variants of a kernel) call select_library() explicitly
+# before the first use.
+LIB_PATH = os.path.join(HERE, "libjjs_gpu.so")
+PROFILING_LIB_PATH = os.path.join(HERE, "libjjs_gpu_prof.so")
 
 _P, _Z, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 
@@ -45,11 +48,16 @@ SIGNATURES = {
     "jjs_debug_fq_mul_dev": [_P, _P, _Z, _P, _P],
     "jjs_debug_poseidon_dev": [_P, _Z, _Z, _P, _P],
     "jjs_debug_point_flags_dev": [_P, _Z, _P, _P],
-    "jjs_debug_skip_phases": [ctypes.c_uint],
+    "jjs_debug_half_scalars_dev": [_P, _Z, _P, _P, _P, _P],
     "jjs_debug_comb_table_bytes": [],
     "jjs_debug_comb_table": [_I, _P],
     "jjs_debug_rccl_selftest": [],
     "jjs_public_keys_dev": [_P, _Z, _P, _P, _P, _P],
+}
+# include/jjs_gpu_profiling.h: present in libjjs_gpu_prof.so only
+PROFILING_SIGNATURES = {
+    "jjs_debug_skip_phases": [ctypes.c_uint],
+    "jjs_debug_allow_virtual_devices": [_I],
 }
 _RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
 
@@ -59,6 +67,18 @@ class JjsError(RuntimeError):
 
 
 _lib = None
+
+
+def select_library(path: str) -> None:
+    """Load another in-tree build of the engine instead of libjjs_gpu.so (profiling build, A/B kernel variants).
+    Only before the first use, and only a libjjs_gpu*.so inside this package directory."""
+    global LIB_PATH
+    path = os.path.abspath(path)
+    if _lib is not None:
+        raise JjsError("select_library() must be called before the library is first used")
+    if os.path.dirname(path) != HERE or not os.path.basename(path).startswith("libjjs_gpu"):
+        raise JjsError(f"{path}: not an in-tree build of the engine")
+    LIB_PATH = path
 
 
 def lib():
@@ -82,6 +102,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the ABI and the header diverge
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, _I)
+        for name, args in PROFILING_SIGNATURES.items():
+            if hasattr(l, name):   # the profiling build only
+                getattr(l, name).argtypes = args
         _lib = l
     return _lib
 

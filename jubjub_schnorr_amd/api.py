@@ -263,6 +263,18 @@ class Engine:
                                                        self._stream()), "jjs_debug_point_flags_dev")
         return out
 
+    def debug_half_scalars(self, c):
+        """(a, |b|, sign of b) the device derives from challenges c (n, 32): (n, 16), (n, 16), (n,) uint8 tensors."""
+        import torch
+        n = c.shape[0]
+        a = torch.empty((max(n, 1), 16), dtype=torch.uint8, device=c.device)[:n]
+        b = torch.empty((max(n, 1), 16), dtype=torch.uint8, device=c.device)[:n]
+        neg = torch.empty(max(n, 1), dtype=torch.uint8, device=c.device)[:n]
+        o = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _ffi.check(self._lib.jjs_debug_half_scalars_dev(self._dev_ptr(c, 32, n), n, o(a), o(b), o(neg), self._stream()),
+                   "jjs_debug_half_scalars_dev")
+        return a, b, neg
+
     def debug_comb_table(self, which: int) -> np.ndarray:
         nbytes = self._lib.jjs_debug_comb_table_bytes()
         out = np.empty(nbytes // 4, np.uint32)

@@ -263,10 +263,10 @@ JJS_CALL raw9 mont_mul_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, 
                             uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
     // one hand-scheduled block (tools/gen_mont_asm.py): 153 multiply-adds in a single accumulator chain +
-    // 36 masks/shifts; the result limb j overwrites a_j
+    // 36 masks/shifts; the result limb j overwrites a_j (hence early-clobber: no b_k may share a register with an a_j)
     asm(JJS_MONT_MUL_ASM
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
-          [a7] "+v"(a7), [a8] "+v"(a8)
+        : [a0] "+&v"(a0), [a1] "+&v"(a1), [a2] "+&v"(a2), [a3] "+&v"(a3), [a4] "+&v"(a4), [a5] "+&v"(a5), [a6] "+&v"(a6),
+          [a7] "+&v"(a7), [a8] "+&v"(a8)
         : [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [b4] "v"(b4), [b5] "v"(b5), [b6] "v"(b6), [b7] "v"(b7),
           [b8] "v"(b8)
         : JJS_MONT_ASM_CLOBBERS);
@@ -281,8 +281,8 @@ JJS_CALL raw9 mont_sqr_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, 
                             uint32_t a6, uint32_t a7, uint32_t a8) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
     asm(JJS_MONT_SQR_ASM
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
-          [a7] "+v"(a7), [a8] "+v"(a8)
+        : [a0] "+&v"(a0), [a1] "+&v"(a1), [a2] "+&v"(a2), [a3] "+&v"(a3), [a4] "+&v"(a4), [a5] "+&v"(a5), [a6] "+&v"(a6),
+          [a7] "+&v"(a7), [a8] "+&v"(a8)
         :
         : JJS_MONT_ASM_CLOBBERS);
     return raw9{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
@@ -303,8 +303,8 @@ JJS_HD raw9 mont_mul_inl(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uin
                          uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
     asm(JJS_MONT_MUL_ASM
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
-          [a7] "+v"(a7), [a8] "+v"(a8)
+        : [a0] "+&v"(a0), [a1] "+&v"(a1), [a2] "+&v"(a2), [a3] "+&v"(a3), [a4] "+&v"(a4), [a5] "+&v"(a5), [a6] "+&v"(a6),
+          [a7] "+&v"(a7), [a8] "+&v"(a8)
         : [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [b4] "v"(b4), [b5] "v"(b5), [b6] "v"(b6), [b7] "v"(b7),
           [b8] "v"(b8)
         : JJS_MONT_ASM_CLOBBERS);
@@ -317,8 +317,8 @@ JJS_HD raw9 mont_sqr_inl(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uin
                          uint32_t a7, uint32_t a8) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_NO_MONT_ASM)
     asm(JJS_MONT_SQR_ASM
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
-          [a7] "+v"(a7), [a8] "+v"(a8)
+        : [a0] "+&v"(a0), [a1] "+&v"(a1), [a2] "+&v"(a2), [a3] "+&v"(a3), [a4] "+&v"(a4), [a5] "+&v"(a5), [a6] "+&v"(a6),
+          [a7] "+&v"(a7), [a8] "+&v"(a8)
         :
         : JJS_MONT_ASM_CLOBBERS);
     return raw9{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -218,6 +219,21 @@ __global__ __launch_bounds__(BLOCK) void dbg_point_flags_kernel(const uint8_t* p
                        (is_torsion_free_by_order(u, v) ? 8 : 0));
 }
 
+// half_size_scalars as the device runs it (v_rcp_f64 estimates, wave ballots for loop control), so that the
+// adversarial inputs of tests/test_hostbuild.py reach the GPU code path too.  Every lane of a wave runs the
+// loop (the last item is repeated in the tail).
+__global__ __launch_bounds__(BLOCK) void dbg_half_scalars_kernel(const uint8_t* c, uint64_t n, uint8_t* a_out, uint8_t* b_out,
+                                                                 uint8_t* neg_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n;
+    const fe_src s{c, 32, 0};
+    const half_scalars h = half_size_scalars(load_words(s, active ? i : n - 1));
+    if (!active) return;
+    reinterpret_cast<u32x4*>(a_out)[i] = u32x4{h.a.w[0], h.a.w[1], h.a.w[2], h.a.w[3]};
+    reinterpret_cast<u32x4*>(b_out)[i] = u32x4{h.b.w[0], h.b.w[1], h.b.w[2], h.b.w[3]};
+    neg_out[i] = h.b_neg ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-device state: everything a launch on that device needs (tables, per-lane workspace, scratch).
 struct device_state {
@@ -246,6 +262,8 @@ struct device_state {
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
+    uint8_t* pinned = nullptr;           // host-buffer calls: pinned host staging (two input slots + statuses, grow-only)
+    size_t pinned_bytes = 0;
     hipEvent_t chunk_up[33] = {}, chunk_done[33] = {};
 };
 
@@ -264,7 +282,6 @@ constexpr int MAX_DEVICES = 16;
 
 struct library_state {
     std::mutex mu;
-    char err[512] = "";
     std::vector<device_state*> devs;       // devices this process drives (jjs_init)
     bool virtual_devices = false;          // test mode: several logical devices on one physical device
     rccl_api rccl;
@@ -272,12 +289,18 @@ struct library_state {
     bool comms_up = false;
 };
 library_state L;
-device_state* g = nullptr;   // device bound to the call in progress (set under L.mu by bind_device)
+// Device bound to the work in progress on THIS host thread: set by check_ready for an entry point and by each
+// per-device worker of run_host for its own block (the workers run concurrently, one device each).
+thread_local device_state* g = nullptr;
+
+// One message buffer per host thread: jjs_last_error() describes the calling thread's last failure and a
+// pointer it returned is never written by another thread.
+thread_local char t_err[512] = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(L.err, sizeof(L.err), fmt, ap);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
     va_end(ap);
     return code;
 }
@@ -300,7 +323,10 @@ int grid_for(int resident, size_t n) {
     return (int)(want < (size_t)resident ? want : (size_t)resident);
 }
 
-uint32_t g_skip_phases = 0;   // set by jjs_debug_skip_phases (profiling ablations only)
+#if defined(JJS_PROFILING)
+uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_prof.so only)
+bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
+#endif
 
 // The per-lane workspace, the wire and the multisig scratch are shared by every call, so launches issued
 // on different streams are ordered one after the other on the device: each waits for the previous user.
@@ -344,7 +370,9 @@ int ensure_prep(size_t n) {
 // only; the grid is sized for the batch, lanes without a queue entry leave at once).
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
+#if defined(JJS_PROFILING)
     P.skip_phases = g_skip_phases;
+#endif
     if (int rc = ensure_pending(P.n)) return rc;
     if (int rc = ensure_prep(P.n)) return rc;
     P.prep = g->prep;
@@ -441,6 +469,7 @@ void free_device(device_state& d) {
                     d.pending, d.stage, d.prep};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (d.pinned) (void)hipHostFree(d.pinned);
     if (d.last_use) (void)hipEventDestroy(d.last_use);
     for (int i = 0; i < 33; ++i) {
         if (d.chunk_up[i]) (void)hipEventDestroy(d.chunk_up[i]);
@@ -521,11 +550,15 @@ struct device_restore {   // puts the calling thread back on the device it came 
 };
 
 // Host-buffer calls.  The batch is cut into one contiguous block of ceil(n / devices) items per driven
-// device (the rule of jubjub_schnorr_amd/sharding.py).  Each block runs as a pipeline of chunks of at least
-// HOST_CHUNK_ITEMS items: chunk c+1 is uploaded on the device's copy stream while chunk c is being verified
-// on its compute stream, and the statuses of chunk c-1 travel back meanwhile.  Inputs, statuses and the
-// events live in a per-device staging arena that only grows.  The tallies accumulate over the chunks and are
-// summed over the devices with one RCCL all-reduce at the end.
+// device (the rule of jubjub_schnorr_amd/sharding.py) and every block is driven by its OWN host thread, so that
+// the uploads of different devices overlap (one thread issuing pageable copies for all devices would stage them
+// one after the other).  A block runs as a pipeline of chunks of at least HOST_CHUNK_ITEMS items: the thread copies
+// chunk c from the caller's (pageable) arrays into one of two pinned staging slots and queues its upload on the
+// device's copy stream while chunk c-1 is being verified on the compute stream and the statuses of chunk c-2
+// travel back into a pinned buffer.  Device arena, pinned staging and events are per device and only grow.  The
+// tallies accumulate over the chunks and are summed over the devices with one RCCL all-reduce at the end.
+// A failing block drains both of its streams before it reports, so nothing is in flight into the caller's or
+// the library's buffers when the call returns an error.
 struct host_col { const uint8_t* p; size_t width; };
 constexpr size_t HOST_CHUNK_ITEMS = size_t(1) << 18;
 constexpr size_t HOST_MAX_CHUNKS = 32;
@@ -543,6 +576,80 @@ int ensure_stage(size_t bytes) {
     g->stage_bytes = bytes;
     return JJS_OK;
 }
+int ensure_pinned(size_t bytes) {
+    if (bytes <= g->pinned_bytes) return JJS_OK;
+    if (g->pinned) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipHostFree(g->pinned));
+        g->pinned = nullptr; g->pinned_bytes = 0;
+    }
+    HIP_TRY(hipHostMalloc(&g->pinned, bytes, hipHostMallocDefault));
+    g->pinned_bytes = bytes;
+    return JJS_OK;
+}
+size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
+
+template <size_t K>
+struct host_block {
+    size_t lo = 0, hi = 0, chunk = 0, chunks = 0;
+    int rc = JJS_OK;
+    char err[512] = "";
+    unsigned long long tally[4] = {0, 0, 0, 0};
+};
+
+// The pipeline of one device's block; runs on the calling thread (one device) or on a thread of its own.
+template <size_t K, typename Launch>
+int run_host_block(device_state* dev, const host_col (&cols)[K], host_block<K>& b, uint8_t* status, Launch& launch) {
+    g = dev;
+    HIP_TRY(hipSetDevice(g->device));
+    const size_t nl = b.hi - b.lo;
+    // device arena: one array per column for the whole block, then the statuses
+    size_t bytes = 0, row = 0;
+    for (size_t k = 0; k < K; ++k) { bytes += pad256(nl * cols[k].width); row += cols[k].width; }
+    bytes += pad256(nl);
+    if (int rc = ensure_stage(bytes ? bytes : 256)) return rc;
+    uint8_t* in[K];
+    uint8_t* p = g->stage;
+    for (size_t k = 0; k < K; ++k) { in[k] = p; p += pad256(nl * cols[k].width); }
+    uint8_t* st = p;
+    // pinned staging: two slots of one chunk of inputs each, then the statuses of the whole block
+    const size_t slot_bytes = pad256(b.chunk * row);
+    if (int rc = ensure_pinned(2 * slot_bytes + pad256(nl) + 256)) return rc;
+    uint8_t* const slot[2] = {g->pinned, g->pinned + slot_bytes};
+    uint8_t* const pst = g->pinned + 2 * slot_bytes;
+    // the arena and the counters may still be in use by the previous call's last launches
+    HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
+    HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
+    for (size_t c = 0; c <= b.chunks; ++c) {
+        if (c < b.chunks) {
+            const size_t off = c * b.chunk, len = (off + b.chunk < nl) ? b.chunk : (nl - off);
+            if (c >= 2) HIP_TRY(hipEventSynchronize(g->chunk_up[c - 2]));      // the slot's previous upload has left it
+            const void* dp[K];
+            uint8_t* hp = slot[c & 1];
+            for (size_t k = 0; k < K; ++k) {
+                const size_t w = cols[k].width;
+                memcpy(hp, cols[k].p + (b.lo + off) * w, len * w);
+                HIP_TRY(hipMemcpyAsync(in[k] + off * w, hp, len * w, hipMemcpyHostToDevice, g->copy_stream));
+                dp[k] = in[k] + off * w;
+                hp += len * w;
+            }
+            HIP_TRY(hipEventRecord(g->chunk_up[c], g->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(g->stream, g->chunk_up[c], 0));
+            if (int rc = launch(dp, len, (void*)(st + off), (void*)g->tally, (void*)g->stream)) return rc;
+            HIP_TRY(hipEventRecord(g->chunk_done[c], g->stream));
+        }
+        if (c > 0 && status) {            // statuses of the previous chunk, behind this chunk's upload
+            const size_t off = (c - 1) * b.chunk, len = (off + b.chunk < nl) ? b.chunk : (nl - off);
+            HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->chunk_done[c - 1], 0));
+            HIP_TRY(hipMemcpyAsync(pst + off, st + off, len, hipMemcpyDeviceToHost, g->copy_stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipStreamSynchronize(g->copy_stream));
+    if (status && nl) memcpy(status + b.lo, pst, nl);
+    return JJS_OK;
+}
 
 template <size_t K, typename Launch>
 int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tally[4], Launch&& launch) {
@@ -551,82 +658,63 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
     std::vector<device_state*> targets;
     if (L.devs.size() == 1) targets.push_back(g); else targets = L.devs;
     const size_t nd = targets.size();
-    struct block { size_t lo = 0, hi = 0, chunk = 0, chunks = 0; uint8_t* in[K] = {}; uint8_t* st = nullptr; };
-    std::vector<block> blocks(nd);
+    std::vector<host_block<K>> blocks(nd);
     device_restore restore;
     struct keep_tally_scope { keep_tally_scope() { g_keep_tally = true; } ~keep_tally_scope() { g_keep_tally = false; } } keep;
     const size_t per = (n + nd - 1) / nd;
-    int rc;
-    size_t max_chunks = 0;
     for (size_t d = 0; d < nd; ++d) {
-        g = targets[d];
-        HIP_TRY(hipSetDevice(g->device));
-        block& b = blocks[d];
+        host_block<K>& b = blocks[d];
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
         const size_t nl = b.hi - b.lo;
         b.chunk = HOST_CHUNK_ITEMS;
         if (nl > b.chunk * HOST_MAX_CHUNKS) b.chunk = ((nl + HOST_MAX_CHUNKS - 1) / HOST_MAX_CHUNKS + 255) & ~size_t(255);
+        if (nl < b.chunk) b.chunk = nl ? nl : 1;                  // small calls pin only what they use
         b.chunks = (nl + b.chunk - 1) / b.chunk;
-        if (b.chunks > max_chunks) max_chunks = b.chunks;
-        size_t bytes = 0;
-        for (size_t k = 0; k < K; ++k) bytes += (nl * cols[k].width + 255) & ~size_t(255);
-        bytes += (nl + 255) & ~size_t(255);
-        if ((rc = ensure_stage(bytes ? bytes : 256))) return rc;
-        uint8_t* p = g->stage;
-        for (size_t k = 0; k < K; ++k) { b.in[k] = p; p += (nl * cols[k].width + 255) & ~size_t(255); }
-        b.st = p;
-        // the arena and the counters may still be in use by the previous call's last launches
-        HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
-        HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
-        HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
     }
-    for (size_t c = 0; c <= max_chunks; ++c) {
-        for (size_t d = 0; d < nd; ++d) {
-            g = targets[d];
-            block& b = blocks[d];
-            if (c > b.chunks || b.chunks == 0) continue;
-            HIP_TRY(hipSetDevice(g->device));
-            if (c < b.chunks) {
-                const size_t off = c * b.chunk, len = (off + b.chunk < b.hi - b.lo) ? b.chunk : (b.hi - b.lo - off);
-                const void* dp[K];
-                for (size_t k = 0; k < K; ++k) {
-                    const size_t w = cols[k].width;
-                    HIP_TRY(hipMemcpyAsync(b.in[k] + off * w, cols[k].p + (b.lo + off) * w, len * w, hipMemcpyHostToDevice,
-                                           g->copy_stream));
-                    dp[k] = b.in[k] + off * w;
-                }
-                HIP_TRY(hipEventRecord(g->chunk_up[c], g->copy_stream));
-                HIP_TRY(hipStreamWaitEvent(g->stream, g->chunk_up[c], 0));
-                if ((rc = launch(dp, len, (void*)(b.st + off), (void*)g->tally, (void*)g->stream))) return rc;
-                HIP_TRY(hipEventRecord(g->chunk_done[c], g->stream));
-            }
-            if (c > 0 && status) {            // statuses of the previous chunk, behind this chunk's upload
-                const size_t off = (c - 1) * b.chunk, len = (off + b.chunk < b.hi - b.lo) ? b.chunk : (b.hi - b.lo - off);
-                HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->chunk_done[c - 1], 0));
-                HIP_TRY(hipMemcpyAsync(status + b.lo + off, b.st + off, len, hipMemcpyDeviceToHost, g->copy_stream));
-            }
+    auto work = [&](size_t d) {
+        host_block<K>& b = blocks[d];
+        b.rc = run_host_block(targets[d], cols, b, status, launch);
+        if (b.rc != JJS_OK) {
+            // leave nothing in flight into the caller's arrays, the pinned slots or the counters
+            (void)hipStreamSynchronize(targets[d]->stream);
+            (void)hipStreamSynchronize(targets[d]->copy_stream);
+            snprintf(b.err, sizeof(b.err), "%s", t_err);
         }
+    };
+    if (nd == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t d = 0; d < nd; ++d) threads.emplace_back(work, d);
+        for (std::thread& t : threads) t.join();
     }
+    g = targets[0];
+    for (size_t d = 0; d < nd; ++d)
+        if (blocks[d].rc != JJS_OK) return fail(blocks[d].rc, "device %d: %s", targets[d]->device, blocks[d].err);
     if (nd > 1 && L.comms_up)
-        if ((rc = allreduce_tallies())) return rc;
-    unsigned long long t[MAX_DEVICES][4] = {};
-    for (size_t d = 0; d < nd; ++d) {
-        g = targets[d];
-        HIP_TRY(hipSetDevice(g->device));
-        HIP_TRY(hipMemcpyAsync(t[d], g->tally, sizeof(t[d]), hipMemcpyDeviceToHost, g->stream));
-    }
+        if (int rc = allreduce_tallies()) {
+            for (size_t d = 0; d < nd; ++d) { (void)hipSetDevice(targets[d]->device); (void)hipStreamSynchronize(targets[d]->stream); }
+            return rc;
+        }
     for (size_t d = 0; d < nd; ++d) {
         HIP_TRY(hipSetDevice(targets[d]->device));
-        HIP_TRY(hipStreamSynchronize(targets[d]->stream));
-        HIP_TRY(hipStreamSynchronize(targets[d]->copy_stream));
+        HIP_TRY(hipMemcpyAsync(blocks[d].tally, targets[d]->tally, sizeof(blocks[d].tally), hipMemcpyDeviceToHost, targets[d]->stream));
+        HIP_TRY(hipEventRecord(targets[d]->last_use, targets[d]->stream));
     }
+    int rc = JJS_OK;
+    for (size_t d = 0; d < nd; ++d) {          // drain every device even if one of them reports an error
+        hipError_t e = hipSetDevice(targets[d]->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(targets[d]->stream);
+        if (e != hipSuccess && rc == JJS_OK) rc = fail(JJS_ERR_HIP, "device %d: %s", targets[d]->device, hipGetErrorString(e));
+    }
+    if (rc != JJS_OK) return rc;
     if (tally) {
-        for (int i = 0; i < 4; ++i) tally[i] = t[0][i];
+        for (int i = 0; i < 4; ++i) tally[i] = blocks[0].tally[i];
         // test mode (logical devices sharing one GPU cannot form an RCCL clique): add the counters here
         if (nd > 1 && !L.comms_up)
             for (size_t d = 1; d < nd; ++d)
-                for (int i = 0; i < 4; ++i) tally[i] += t[d][i];
+                for (int i = 0; i < 4; ++i) tally[i] += blocks[d].tally[i];
     }
     return JJS_OK;
 }
@@ -635,8 +723,8 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
 
 extern "C" {
 
-int jjs_abi_version(void) { return 2; }
-const char* jjs_last_error(void) { return L.err; }
+int jjs_abi_version(void) { return 3; }
+const char* jjs_last_error(void) { return t_err; }
 
 int jjs_init(int device_count) {
     std::lock_guard<std::mutex> lock(L.mu);
@@ -646,8 +734,11 @@ int jjs_init(int device_count) {
     HIP_TRY(hipGetDeviceCount(&visible));
     HIP_TRY(hipGetDevice(&current));
     if (visible < 1) return fail(JJS_ERR_HIP, "no HIP device visible");
-    const char* virt = getenv("JJS_DEBUG_VIRTUAL_DEVICES");
-    const bool allow_virtual = virt && virt[0] == '1';
+#if defined(JJS_PROFILING)
+    const bool allow_virtual = g_allow_virtual;   // logical devices sharing one card: test builds only
+#else
+    const bool allow_virtual = false;
+#endif
     const int want = device_count == 0 ? visible : device_count;
     if (!L.devs.empty()) {   // idempotent for the same request
         if (device_count == 1) return check_ready();
@@ -682,8 +773,11 @@ int jjs_device_count(void) {
 }
 
 int jjs_stream_sync(void* stream) {
-    if (L.devs.empty()) return fail(JJS_ERR_NOT_INIT, "jjs_init has not been called");
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        if (L.devs.empty()) return fail(JJS_ERR_NOT_INIT, "jjs_init has not been called");
+    }
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));     // waits without holding the engine's mutex
     return JJS_OK;
 }
 
@@ -1084,11 +1178,29 @@ int jjs_debug_point_flags_dev(const void* points, size_t n, void* out, void* str
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }
+int jjs_debug_half_scalars_dev(const void* c, size_t n, void* a_out, void* b_out, void* b_neg_out, void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return JJS_OK;
+    if (!all_ok(c, a_out, b_out) || !b_neg_out) return fail(JJS_ERR_ARG, "null or misaligned pointer");
+    hipLaunchKernelGGL(dbg_half_scalars_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t*)c, (uint64_t)n, (uint8_t*)a_out, (uint8_t*)b_out, (uint8_t*)b_neg_out);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+#if defined(JJS_PROFILING)
+// include/jjs_gpu_profiling.h: these two exist only in libjjs_gpu_prof.so
 int jjs_debug_skip_phases(unsigned mask) {
     std::lock_guard<std::mutex> lock(L.mu);
     g_skip_phases = mask & 15u;
     return JJS_OK;
 }
+int jjs_debug_allow_virtual_devices(int allow) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    g_allow_virtual = allow != 0;
+    return JJS_OK;
+}
+#endif
 // Loads RCCL, forms a one-rank clique on the current device and sums a known 4 x u64 vector in place: checks
 // the library, the symbols and the call sequence of allreduce_tallies() on a box with a single GPU.
 int jjs_debug_rccl_selftest(void) {

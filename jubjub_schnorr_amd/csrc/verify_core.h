@@ -48,7 +48,11 @@ struct eq_desc {           // u*Gen + c*PK == R
 };
 struct verify_params {
     uint32_t n_hash, n_points, n_eq;
-    uint32_t skip_phases;            // profiling only (bit0 validity, bit1 challenge, bit2 equations, bit3 Euclid); 0 in production
+#if defined(JJS_PROFILING)
+    uint32_t skip_phases;            // profiling build only (bit0 validity, bit1 challenge, bit2 equations, bit3 Euclid)
+#else
+    uint32_t pad0_;                  // the product build has no ablation switch: see JJS_SKIP below
+#endif
     fe_src hash_in[10];
     fe_src points[4];
     eq_desc eq[2];
@@ -66,6 +70,14 @@ struct verify_params {
     uint64_t* pending;               // queue of items left to the resolve pass: item << 1 | equations held
     unsigned long long* pending_count;
 };
+
+// Ablation switches for tools/phase_profile.py exist only in the profiling build (libjjs_gpu_prof.so); in the
+// product library the test is the constant `false`, so no value of any field can turn a check off.
+#if defined(JJS_PROFILING)
+#define JJS_SKIP(P, bits) (((P).skip_phases & (bits)) != 0u)
+#else
+#define JJS_SKIP(P, bits) false
+#endif
 
 constexpr int TABLE_ENTRIES = 9;                 // {0..8} * P
 constexpr int ENTRY_WORDS = 36;                  // 4 coordinates x 9 limbs
@@ -314,9 +326,17 @@ JJS_HD uint64_t bits64_at(const uint32_t (&x)[8], int pos) {
     return pos < 0 ? (v << (-pos)) : v;
 }
 
+// Reciprocal ESTIMATE only.  v_rcp_f64 is not correctly rounded (treat it as good to ~2^-23 relative, the
+// figure older ISA manuals give); nothing below relies on its accuracy for correctness: the remainder
+// xn = x - q*ys is computed exactly (fma on integers below 2^53 whose true result is below 2^53), a quotient
+// that is off by one is repaired from the sign / size of xn, and a step is accepted only after the explicit
+// range certificate `xn >= cn && ys - xn >= cn + c1`, which implies 0 <= xn < ys, i.e. that q IS floor(x / ys).
+// A worse estimate therefore ends the lane's Lehmer run early (the caller falls back to the full-precision
+// step), it cannot produce a wrong step.  tests/test_gpu_parity.py::test_half_size_scalars_on_device and the
+// Euclid stage of tools/devcheck run this code path on the device against the textbook algorithm.
 JJS_HD double rcp_estimate(double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcp(y);      // 1 ulp is enough: the quotient estimate is corrected below
+    return __builtin_amdgcn_rcp(y);
 #else
     return 1.0 / y;
 #endif
@@ -345,7 +365,7 @@ JJS_HD lehmer_run lehmer_steps(double x, double y, double th, bool live) {
         bool ok = live && y >= th + c1;
         const double ys = ok ? y : 1.0;
         double q = ::floor(x * rcp_estimate(ys));
-        double xn = ::fma(-q, ys, x);                 // exact; the estimate is off by at most one when q < 2^26
+        double xn = ::fma(-q, ys, x);                 // exact (see rcp_estimate); one unit of error in q is repaired here
         const bool low = xn < 0.0, high = xn >= ys;
         q = low ? q - 1.0 : (high ? q + 1.0 : q);
         xn = low ? xn + ys : (high ? xn - ys : xn);
@@ -707,7 +727,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     r.malformed = malformed;
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
-    const bool check_points = !(P.skip_phases & 1u);
+    const bool check_points = !JJS_SKIP(P, 1u);
     bool valid = true;
     for (uint32_t k = 0; k < (check_points ? P.n_points : 0u); ++k) {
         fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
@@ -719,7 +739,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
 
     // 3. challenge
     words8 c = u;
-    if (!(P.skip_phases & 2u)) {
+    if (!JJS_SKIP(P, 2u)) {
         fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
         c = truncate250(digest);
     }
@@ -727,10 +747,10 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     r.c = c;
 
     // 4. half-size scalars (shared by both equations of the double scheme) and the combined subgroup tests
-    const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
+    const uint32_t n_eq = JJS_SKIP(P, 4u) ? 0u : P.n_eq;
     half_scalars h{};
     if (n_eq && P.eq[0].comb) {
-        if (P.skip_phases & 8u) {                           // profiling only: stand-in scalars, no Euclid
+        if (JJS_SKIP(P, 8u)) {                           // profiling only: stand-in scalars, no Euclid
 #pragma unroll
             for (int i = 0; i < 4; ++i) { h.a.w[i] = c.w[i] >> 2; h.b.w[i] = c.w[4 + i] >> 2; }
         } else {
@@ -749,11 +769,11 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
 JJS_HD uint32_t finish_item(const verify_params& P, uint64_t item, uint32_t* ws, const prep_record& r) {
     const words8 u = load_words(P.u, item);
     bool eq_ok = true;
-    const uint32_t n_eq = (P.skip_phases & 4u) ? 0u : P.n_eq;
+    const uint32_t n_eq = JJS_SKIP(P, 4u) ? 0u : P.n_eq;
     for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, r.c, r.h) && eq_ok;
     if (r.malformed) return ST_MALFORMED;
     if (!r.valid) return ST_INVALID_POINT;
-    if (P.skip_phases & 1u) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;
+    if (JJS_SKIP(P, 1u)) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;
     if (eq_ok && r.proven) return ST_OK;
     return eq_ok ? ST_PENDING_EQ_HELD : ST_PENDING_EQ_FAILED;
 }

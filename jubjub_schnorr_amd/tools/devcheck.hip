@@ -28,10 +28,10 @@ constexpr int N = 512;
 constexpr int OUT_WORDS = 64;   // per item per stage
 
 enum Stage { S_MUL, S_SQR, S_ADDSUB, S_REDUCE, S_DOT5, S_SBOX, S_ROUND_FULL, S_ROUND_PARTIAL, S_PERMUTE, S_DOUBLE, S_ADD,
-             S_ONCURVE, S_TORSION, S_CANON, N_STAGES };
+             S_ONCURVE, S_TORSION, S_CANON, S_EUCLID, N_STAGES };
 static const char* kStageNames[] = {"mul", "sqr", "add/sub/norm", "reduce", "dot5", "sbox", "hades round (full)",
                                     "hades round (partial)", "hades permute", "ext_double", "ext_add_niels", "on_curve",
-                                    "torsion", "canon/to_words"};
+                                    "torsion", "canon/to_words", "half-size scalars (Euclid)"};
 
 __host__ __device__ inline void put(uint32_t* out, int& pos, const uint32_t* l, int n) { for (int i = 0; i < n; ++i) out[pos++] = l[i]; }
 
@@ -93,6 +93,13 @@ __host__ __device__ inline void run_stage(int stage, const uint32_t* in, uint32_
     case S_ONCURVE: { out[0] = affine_on_curve(a, b); out[1] = affine_is_identity(a, b); out[2] = fq_is_zero(fq_sub(a, a)); break; }
     case S_TORSION: { out[0] = is_torsion_free(a, b); break; }
     case S_CANON: { words8 r = fq_to_words(fq_add(fq_add(a, b), c)); put(out, pos, r.w, 8); break; }
+    case S_EUCLID: {
+        // the device takes v_rcp_f64 estimates and wave ballots, the host 1.0 / y and per-lane control: same (a, b)
+        words8 cw = w[0];
+        cw.w[7] &= 0x03ffffffu;                                   // a challenge: 250 bits
+        half_scalars h = half_size_scalars(cw);
+        put(out, pos, h.a.w, 4); put(out, pos, h.b.w, 4); out[pos++] = h.b_neg ? 1u : 0u;
+        break; }
     }
 }
 
@@ -113,6 +120,21 @@ int main() {
         fe_n gu = fq_as<1, 2>(fe_from_const<1, 1>(JJS_G[0])), gv = fq_as<1, 2>(fe_from_const<1, 1>(JJS_G[1]));
         words8 a = fq_to_words(gu), b = fq_to_words(gv);
         memcpy(&in[80], a.w, 32); memcpy(&in[88], b.w, 32);
+    }
+    // items 3..10: challenges with huge first quotients (r >> k) and remainders next to 2^126 (the Euclid stage)
+    {
+        const int shifts[6] = {26, 31, 32, 63, 120, 125};
+        for (int t = 0; t < 6; ++t) {
+            uint32_t x[8];
+            for (int k = 0; k < 8; ++k) x[k] = JJS_FR_WORDS[k];
+            for (int sft = 0; sft < shifts[t]; ++sft) {                  // x >>= 1
+                for (int k = 0; k < 8; ++k) x[k] = (x[k] >> 1) | (k < 7 ? x[k + 1] << 31 : 0u);
+            }
+            x[0] += (t & 1);
+            memcpy(&in[40 * (3 + t)], x, 32);
+        }
+        uint32_t p126[8] = {0, 0, 0, 0x40000000u, 0, 0, 0, 0}, m126[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu, 0, 0, 0, 0};
+        memcpy(&in[40 * 9], p126, 32); memcpy(&in[40 * 10], m126, 32);
     }
     uint32_t *din, *dout;
     CHECK(hipMalloc(&din, in.size() * 4)); CHECK(hipMalloc(&dout, (size_t)OUT_WORDS * N * 4));

@@ -17,6 +17,7 @@ from jubjub_schnorr_amd import _ffi  # noqa: E402
 def main():
     scheme = sys.argv[1] if len(sys.argv) > 1 else "single"
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    _ffi.select_library(_ffi.PROFILING_LIB_PATH)      # the ablation switches exist only in the -DJJS_PROFILING build
     eng = jjs.engine()
     arrays, _ = bench.make_inputs(eng, scheme, 1 << log2n, 0)
     call = [arrays[k] for k in bench.ARG_ORDER[scheme]]

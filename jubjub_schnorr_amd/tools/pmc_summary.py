@@ -1,6 +1,7 @@
 """Assemble profiles/<tag>_pmc_summary.json and profiles/pmc_latest.json from rocprofv3 CSV output.
 
     python jubjub_schnorr_amd/tools/pmc_summary.py <tag> <variant text> <trace_dir> <pmc_dir> [<pmc_dir> ...]
+    (JJS_PMC_SCHEME=double|vargen in the environment when the passes ran `bench.py --scheme <that>`)
 
 <trace_dir>: output of  rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
 <pmc_dir>s : outputs of rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py ...   (one pass per
@@ -53,19 +54,25 @@ def read_stats(d):
     return out
 
 
+ALGO_BYTES = {"single": 196, "double": 324, "vargen": 260}
+
+
 def main():
     tag, variant, trace_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
+    scheme = os.environ.get("JJS_PMC_SCHEME", "single")
+    sys.path.insert(0, ROOT)
+    import bench
     stats = read_stats(trace_dir)
     counters, meta = {}, {}
     for d in pmc_dirs:
         c, m = read_counters(d)
         counters.update(c)
         meta = m or meta
-    summary = {"round": 1, "variant": variant,
-               "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+    summary = {"round": 2, "variant": variant, "csrc_sha256": bench.csrc_hash(),
+               "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --scheme " + scheme + " --steps 3 --warmup 1 "
                           "--no-cpu-baseline (one pass per counter group); kernel times from a separate "
                           "rocprofv3 --kernel-trace --stats run",
-               "kernels": list(KERNELS), "scheme": "single", "items": 1 << 20, "counters": {}}
+               "kernels": list(KERNELS), "scheme": scheme, "items": 1 << 20, "counters": {}}
     per_batch = {}
     for name, by_kernel in sorted(counters.items()):
         entry = {}
@@ -84,7 +91,7 @@ def main():
         summary["hbm_bytes_per_launch"] = (2.0 * per_batch["FETCH_SIZE"] + per_batch["WRITE_SIZE"]) * 1024.0
         summary["hbm_bytes_note"] = ("FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md HBM section (16 B/lane loads; "
                                      "gather-like access, so an upper estimate), WRITE_SIZE (KB) as is; verify + resolve")
-    summary["algorithmic_bytes_per_launch"] = 196 * (1 << 20)
+    summary["algorithmic_bytes_per_launch"] = ALGO_BYTES[scheme] * (1 << 20)
     if "SQ_INSTS_VALU" in per_batch:
         valu = per_batch["SQ_INSTS_VALU"]
         summary["valu_wave_instr_per_launch"] = valu
@@ -93,12 +100,21 @@ def main():
             cycles = per_batch["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
             summary["effective_clock_ghz"] = cycles / (batch_ms * 1e-3) / 1e9
             summary["cycles_per_valu_instr_per_simd"] = cycles * 1024 / valu
-    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+    suffix = "" if scheme == "single" else "_" + scheme
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary{suffix}.json")
     json.dump(summary, open(out, "w"), indent=1)
-    latest = {"scheme": "single", "items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
-              "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
-              "source": f"profiles/{tag}_pmc_summary.json"}
-    json.dump(latest, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    # profiles/pmc_latest.json: what bench.py may quote -- only for the code it was measured on (csrc hash)
+    latest_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        latest = json.load(open(latest_path))
+    except (OSError, ValueError):
+        latest = {}
+    if latest.get("csrc_sha256") != summary["csrc_sha256"]:
+        latest = {"csrc_sha256": summary["csrc_sha256"], "schemes": {}}
+    latest["schemes"][scheme] = {"items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
+                                 "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
+                                 "source": f"profiles/{tag}_pmc_summary{suffix}.json"}
+    json.dump(latest, open(latest_path, "w"), indent=1)
     print(json.dumps({k: summary[k] for k in summary if k not in ("counters",)}, indent=1))
 
 

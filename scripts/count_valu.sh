@@ -4,8 +4,8 @@
 # Usage (through gpurun): bash scripts/count_valu.sh [scheme] [path/to/variant.so]
 S=${1:-single}; LIB=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; D=$R/gpurun_out/valu_$$; cd /tmp && export TMPDIR=/tmp
-if [ -n "$LIB" ]; then export JJS_GPU_LIB=$LIB; fi
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $D -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --scheme $S > /dev/null 2>&1
+if [ -n "$LIB" ]; then LIBARG="--lib $LIB"; fi
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $D -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --scheme $S $LIBARG > /dev/null 2>&1
 cd $R && python3 - "$D" <<'PY'
 import csv, glob, sys
 tot = {}

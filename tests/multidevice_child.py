@@ -1,6 +1,6 @@
 """Child process of test_multidevice.py: one process driving several (logical) devices through the
-host-buffer entry points.  Run with JJS_DEBUG_VIRTUAL_DEVICES=1 on a one-GPU box, where the logical
-devices share the card (sharding, staging and status scatter are the real code; the tally sum is done on
+host-buffer entry points.  Loads the profiling build of the engine (libjjs_gpu_prof.so) and switches its
+logical-device mode on, so that on a one-GPU box the logical devices share the card (sharding, staging and status scatter are the real code; the tally sum is done on
 the host because two ranks on one card cannot form an RCCL clique)."""
 import os
 import sys
@@ -17,6 +17,10 @@ from test_gpu_parity import to_wire  # noqa: E402
 def main(devices: int) -> None:
     import torch
     import jubjub_schnorr_amd as jjs
+    from jubjub_schnorr_amd import _ffi
+    if torch.cuda.device_count() < devices:
+        _ffi.select_library(_ffi.PROFILING_LIB_PATH)
+        assert _ffi.lib().jjs_debug_allow_virtual_devices(1) == 0
     eng = jjs.Engine(devices)
     assert eng.device_count == devices, eng.device_count
     for scheme in ("single", "double", "vargen"):

@@ -3,14 +3,16 @@ No compute calls here (no GPU)."""
 import ctypes
 import os
 import re
+import subprocess
+import threading
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "jjs_gpu.h")).read()
+def header_symbols(name="jjs_gpu.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(jjs_[a-z0-9_]+)\s*\(", text)))
 
@@ -30,7 +32,44 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.jjs_abi_version() == 2
+    assert lib.jjs_abi_version() == 3
+
+
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_product_library_has_no_bypass_switch():
+    """The ablation switches and the logical-device mode are compiled out of libjjs_gpu.so; they exist only in
+    the -DJJS_PROFILING build, which declares them in include/jjs_gpu_profiling.h."""
+    from jubjub_schnorr_amd import _ffi
+    prof_syms = header_symbols("jjs_gpu_profiling.h")
+    assert prof_syms == ["jjs_debug_allow_virtual_devices", "jjs_debug_skip_phases"] == sorted(_ffi.PROFILING_SIGNATURES)
+    product = exported(os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so"))
+    for s in prof_syms:
+        assert s not in product, s
+    assert not any("skip" in s or "virtual" in s for s in product if s.startswith("jjs_"))
+    # no string of the product binary names an environment switch
+    blob = open(os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so"), "rb").read()
+    assert b"JJS_DEBUG" not in blob and b"JJS_GPU_LIB" not in blob
+    prof = exported(_ffi.PROFILING_LIB_PATH)
+    for s in prof_syms + header_symbols():
+        assert s in prof, s
+
+
+def test_loader_ignores_the_environment(monkeypatch, tmp_path):
+    monkeypatch.setenv("JJS_GPU_LIB", str(tmp_path / "evil.so"))
+    import importlib
+    from jubjub_schnorr_amd import _ffi
+    fresh = importlib.reload(_ffi)
+    try:
+        assert fresh.LIB_PATH == os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so")
+        with pytest.raises(fresh.JjsError):
+            fresh.select_library(str(tmp_path / "libjjs_gpu_evil.so"))       # not inside the package
+    finally:
+        monkeypatch.delenv("JJS_GPU_LIB")
+        importlib.reload(_ffi)
 
 
 def test_python_binding_covers_the_header():
@@ -55,3 +94,34 @@ def test_calls_before_init_report_not_initialised():
     lib.jjs_shutdown()
     assert lib.jjs_stream_sync(None) == -4
     assert b"jjs_init" in lib.jjs_last_error()
+
+
+def test_last_error_is_per_thread():
+    """Two host threads provoking different argument errors at once: each reads its own message, and a pointer
+    obtained earlier is not rewritten by the other thread (include/jjs_gpu.h: threading)."""
+    from jubjub_schnorr_amd import _ffi
+    lib = _ffi.lib()
+    lib.jjs_shutdown()
+    errors = []
+
+    def worker(bad_count, needle):
+        try:
+            for _ in range(2000):
+                assert lib.jjs_init(bad_count) == -1
+                msg = lib.jjs_last_error()
+                assert needle in msg, (needle, msg)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(-7, b"got -7")), threading.Thread(target=worker, args=(99, b"got 99")),
+          threading.Thread(target=worker, args=(-3, b"got -3"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:1]
+    # a thread that never failed sees an empty message
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.jjs_last_error()))
+    t.start(); t.join()
+    assert seen == [b""]

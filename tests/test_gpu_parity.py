@@ -77,6 +77,23 @@ def test_point_flags(eng):
     assert (want[:8] == [3, 1, 1, 1, 1, 1, 1, 1]).all()
 
 
+def test_half_size_scalars_on_device(eng):
+    """The Euclid of the verify kernels on the code path the GPU takes (v_rcp_f64 quotient estimates, wave-ballot
+    loop control): random and adversarial challenges, compared with the textbook truncated Euclid.  Also with the
+    adversarial items spread so that they share waves with ordinary ones (the loop runs until the slowest lane)."""
+    from test_hostbuild import check_half_size, half_size_cases
+    c, n_special = half_size_cases()
+    a, b, neg = (host(t) for t in eng.debug_half_scalars(dev(c)))
+    check_half_size(c, a, b, neg)
+    perm = np.random.default_rng(3).permutation(len(c))
+    a2, b2, neg2 = (host(t) for t in eng.debug_half_scalars(dev(c[perm])))
+    assert (a2 == a[perm]).all() and (b2 == b[perm]).all() and (neg2 == neg[perm]).all()
+    # ragged sizes: a one-lane wave and a partly filled last wave
+    for n in (1, 65):
+        a3, b3, neg3 = (host(t) for t in eng.debug_half_scalars(dev(c[:n])))
+        assert (a3 == a[:n]).all() and (b3 == b[:n]).all() and (neg3 == neg[:n]).all()
+
+
 def test_comb_tables(eng):
     RPI = pow(1 << 261, -1, o.Q)
     for which, base in ((0, o.G), (1, o.G_NUMS)):

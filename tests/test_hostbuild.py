@@ -100,30 +100,58 @@ def test_every_torsion_component_is_caught(scheme):
     assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
 
 
-def test_half_size_scalars():
-    """a = b*c (mod r) with a, |b| < 2^126, for random and adversarial c."""
+def half_size_cases():
+    """Challenges for the truncated Euclid: random ones plus inputs that force huge partial quotients, remainders
+    next to 2^126 and the uncertified-step fallback of the Lehmer loop."""
     rng = np.random.default_rng(12)
     c = rand_mod(rng, 3000, 1 << 250)
-    specials = [0, 1, 2, (1 << 126) - 1, 1 << 126, (1 << 126) + 1, (1 << 250) - 1, o.R_ORDER - 1, o.R_ORDER // 2,
-                (o.R_ORDER + 1) // 2, 1 << 127, 1 << 200, 3 << 248, o.R_ORDER - (1 << 126), (1 << 125) + 12345]
+    R = o.R_ORDER
+    specials = [0, 1, 2, (1 << 126) - 1, 1 << 126, (1 << 126) + 1, (1 << 250) - 1, R - 1, R // 2,
+                (R + 1) // 2, 1 << 127, 1 << 200, 3 << 248, R - (1 << 126), (1 << 125) + 12345]
+    # c = floor(r / k) and neighbours: the first quotient is k (up to 2^120: far beyond the 2^26 a Lehmer run certifies)
+    for k in (3, 1 << 26, (1 << 26) - 1, (1 << 26) + 1, 1 << 31, (1 << 31) + 1, 1 << 32, 1 << 63, 1 << 120, 1 << 125):
+        specials += [R // k, R // k + 1]
+    # continued fractions with a run of ones (slowest convergence), then one huge quotient
+    a, b = 1, 1
+    for _ in range(120):
+        a, b = a + b, a
+    specials += [R * b // a, (R * b // a) | 1, (R >> 124) << 123]
+    # remainders that land within a few units of 2^126 after one step: c = (r - (2^126 + d)) / q for small q
+    for d in (-2, -1, 0, 1, 2):
+        for q in (1, 2, 5):
+            specials.append((R - ((1 << 126) + d)) // q)
+    specials = [x % R for x in specials]
     for i, x in enumerate(specials):
         c[i] = fe_bytes(x)
-    out = hl.half_size(c)
+    return c, len(specials)
+
+
+def check_half_size(c, a_bytes, b_bytes, neg):
+    """a = b*c (mod r), a, |b| < 2^126, b != 0, and (a, b) is exactly where the textbook Euclid on (r, c) first
+    drops below 2^126: every step the implementation takes (single- or multi-quotient, on truncated operands) must
+    be a true Euclid step."""
     for i in range(len(c)):
         ci = to_int(c[i])
-        a = int.from_bytes(out[i, :16].tobytes(), "little")
-        b = int.from_bytes(out[i, 16:32].tobytes(), "little")
-        if out[i, 32]:
+        a = int.from_bytes(bytes(a_bytes[i]), "little")
+        b = int.from_bytes(bytes(b_bytes[i]), "little")
+        if neg[i]:
             b = -b
         assert 0 <= a < 1 << 126 and 0 < abs(b) < 1 << 126, (i, a, b)
         assert (a - b * ci) % o.R_ORDER == 0, i
-        # and it is exactly where Euclid's algorithm on (r, c) first drops below 2^126: every step the
-        # implementation takes (single- or multi-quotient, on truncated operands) must be a true Euclid step
         r0, r1, t0, t1 = o.R_ORDER, ci, 0, 1
         while r1 >= 1 << 126:
             q = r0 // r1
             r0, r1, t0, t1 = r1, r0 - q * r1, t1, t0 - q * t1
         assert (a, b) == (r1, t1), i
+
+
+def test_half_size_scalars():
+    """The CPU build of half_size_scalars (1.0 / y estimates, per-lane loop control); the device code path (v_rcp_f64,
+    wave ballots) runs the same cases in tests/test_gpu_parity.py::test_half_size_scalars_on_device."""
+    c, n_special = half_size_cases()
+    assert n_special >= 15 and len(c) >= 3000
+    out = hl.half_size(c)
+    check_half_size(c, out[:, :16], out[:, 16:32], out[:, 32])
 
 
 def wire_point_cases(rng, n_random=64):

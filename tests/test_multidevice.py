@@ -28,8 +28,8 @@ def test_rccl_call_sequence_on_one_device():
 @pytest.mark.gpu
 @pytest.mark.parametrize("devices", [3])
 def test_host_batches_are_sharded_over_logical_devices(devices):
-    env = dict(os.environ, JJS_DEBUG_VIRTUAL_DEVICES="1")
-    p = subprocess.run([sys.executable, os.path.join(HERE, "multidevice_child.py"), str(devices)], env=env,
+    # the child loads the profiling build (libjjs_gpu_prof.so): only that one can put logical devices on one card
+    p = subprocess.run([sys.executable, os.path.join(HERE, "multidevice_child.py"), str(devices)],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "MULTIDEVICE OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
@@ -39,8 +39,6 @@ def test_more_devices_than_visible_is_refused():
     import torch
     import jubjub_schnorr_amd as jjs
     eng = jjs.engine()
-    if os.environ.get("JJS_DEBUG_VIRTUAL_DEVICES") == "1":
-        pytest.skip("virtual devices enabled")
     eng._lib.jjs_shutdown()
     try:
         assert eng._lib.jjs_init(torch.cuda.device_count() + 1) == -1
