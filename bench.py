@@ -36,6 +36,7 @@ SEED = 0x6A6A73
 N_KEYS = 4096
 ALGO_BYTES = {"single": 196, "double": 324, "vargen": 260}   # bytes in + status out per verify
 WIRE_BYTES = {"single": 132, "double": 196, "vargen": 164}   # the same through the wire entry points
+EXT_BYTES = {"single": 260, "double": 452, "vargen": 356}    # points as U || V || Z (96 B) through the _ext entry points
 HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
 Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 ARG_ORDER = {"single": ["u", "R", "PK", "m"], "double": ["u", "R", "Rp", "PK", "PKp", "m"],
@@ -118,7 +119,39 @@ def host_info():
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = os.cpu_count() or 1
-    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity_cores": affinity}
+    quota = None                      # cgroup CPU bandwidth limit in cores, when the box sets one
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            a, b = parse(open(path).read())
+            if b is None:
+                b = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if a not in ("max", "-1"):
+                quota = int(a) / int(b)
+            break
+        except (OSError, ValueError):
+            continue
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity_cores": affinity, "cgroup_cpu_quota_cores": quota}
+
+
+def pick_threads(run, info, max_threads: int) -> tuple:
+    """The thread count that verifies a probe fastest, among the cores this process may use (affinity, cgroup
+    quota) and halvings of it: a box that shares its sockets runs the oracle slower on 128 threads than on 16."""
+    cap = max(1, min(info["affinity_cores"], max_threads))
+    if info.get("cgroup_cpu_quota_cores"):
+        cap = max(1, min(cap, int(info["cgroup_cpu_quota_cores"] + 0.999)))
+    cands, t = [], cap
+    while t >= 1 and len(cands) < 5:
+        cands.append(t)
+        t //= 2
+    best = (0.0, 1)
+    rates = {}
+    for t in cands:
+        r = run(t)
+        rates[t] = r
+        if r > best[0]:
+            best = (r, t)
+    return best[1], best[0], rates
 
 
 def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budget_s: float = 12.0):
@@ -132,12 +165,15 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
         native = False
     fn = {"single": oc.verify_single, "double": oc.verify_double, "vargen": oc.verify_vargen}[scheme]
     info = host_info()
-    threads = max(1, min(info["affinity_cores"], oc.max_threads(native)))     # every core this process may use
-    probe = 2048
+    probe = 4096
     host = {k: arrays[k][:probe].cpu().numpy() for k in ARG_ORDER[scheme]}
-    t0 = time.perf_counter()
-    fn(*[host[k] for k in ARG_ORDER[scheme]], threads=threads, native=native)
-    rate = probe / (time.perf_counter() - t0)
+
+    def probe_rate(t):
+        t0 = time.perf_counter()
+        fn(*[host[k] for k in ARG_ORDER[scheme]], threads=t, native=native)
+        return probe / (time.perf_counter() - t0)
+
+    threads, rate, probe_rates = pick_threads(probe_rate, info, oc.max_threads(native))
     n = int(min(arrays["u"].shape[0], max(probe, rate * budget_s)))
     host = {k: arrays[k][:n].cpu().numpy() for k in ARG_ORDER[scheme]}
     t0 = time.perf_counter()
@@ -157,6 +193,8 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
         c_agree = bool((c[canonical] == gpu_challenge[:k].cpu().numpy()[canonical]).all())
     return {"value": n / dt, "unit": "verifications/s", "cores": threads, "threads_used": threads, "kind": "port",
             "cpu_model": info["cpu_model"], "nproc": info["nproc"], "affinity_cores": info["affinity_cores"],
+            "cgroup_cpu_quota_cores": info["cgroup_cpu_quota_cores"],
+            "thread_probe": {str(k): round(v) for k, v in probe_rates.items()},
             "sample": f"first {n} items of the same {scheme} batch, oracle/jjs_oracle.c "
                       f"({'-march=native' if native else 'generic x86-64'}, OpenMP, {threads} threads), {dt:.1f} s",
             "one_thread": {"value": one_thread, "items": k1, "config": "BASELINE.json configs[0]: 1 024 signatures, CPU only"},
@@ -224,9 +262,23 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
             wire = [torch.cat([arrays["u"], c["R"]], 1), torch.cat([c["PK"], c["Gen"]], 1), arrays["m"]]
         wire = [w.contiguous() for w in wire]
         torch.cuda.synchronize()
+    if args.ext:          # every point as (U, V, Z) with a per-item Z: what the Rust types hold (jjs_verify_*_ext_dev)
+        zgen = torch.Generator(device="cpu").manual_seed(SEED + 1 + rank)
+
+        def to_ext(pts):
+            z = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=zgen)
+            z[:, 31] &= 0x3F; z[:, 0] |= 1
+            z = z.cuda()
+            U = eng.debug_fq_mul(pts[:, :32].contiguous(), z)
+            V = eng.debug_fq_mul(pts[:, 32:].contiguous(), z)
+            return torch.cat([U, V, z], 1).contiguous()
+        ext = [to_ext(arrays[k]) if arrays[k].shape[1] == 64 else arrays[k] for k in ARG_ORDER[scheme]]
+        torch.cuda.synchronize()
     want_tally = torch.stack([(expect == k).sum() for k in range(4)]).to(torch.int64)
 
     def run_verify():
+        if args.ext:
+            return eng.verify_ext(scheme, *ext)
         return eng.verify_wire(scheme, *wire) if args.wire else eng.verify(scheme, *call)
 
     def fence():
@@ -269,10 +321,10 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     if rank != 0:
         return None, ok
 
-    algo_bytes = WIRE_BYTES[scheme] if args.wire else ALGO_BYTES[scheme]
+    algo_bytes = WIRE_BYTES[scheme] if args.wire else (EXT_BYTES[scheme] if args.ext else ALGO_BYTES[scheme])
     achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
     traffic, alu = None, None
-    pmc = None if args.wire else committed_pmc(scheme, n)
+    pmc = None if (args.wire or args.ext) else committed_pmc(scheme, n)
     if pmc:
         traffic = pmc.get("hbm_bytes_per_launch")
         # the binding roofline: VALU issue.  Instruction count per launch from the committed PMC pass
@@ -294,7 +346,7 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes * n,
-                     "kernel": ("decode_kernel + " if args.wire else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
+                     "kernel": ("decode_kernel + " if args.wire else "normalize_kernel + " if args.ext else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
                      "kernel_ms": kernel_ms,
                      "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6; "
                              "traffic / alu_roofline are null unless profiles/pmc_latest.json was measured on this csrc hash"},
@@ -318,6 +370,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wire", action="store_true",
                     help="feed the reference's wire formats (compressed points, decoded on the device)")
+    ap.add_argument("--ext", action="store_true",
+                    help="feed extended coordinates (U, V, Z per point, normalised on the device)")
     ap.add_argument("--lib", default=None, help="another in-tree build of the engine (A/B timing of kernel variants)")
     args = ap.parse_args()
 
@@ -369,7 +423,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": head["workload"], "scheme": schemes[0], "items_per_gpu": head["items_per_gpu"],
                        "global_items": head["items_per_gpu"] * world,
-                       "input_format": "wire (compressed points)" if args.wire else "affine",
+                       "input_format": "wire (compressed points)" if args.wire else "extended (U, V, Z)" if args.ext else "affine",
                        "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
                        "distributed": {"backend": backend, "world_size": world},
                        "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points"},

@@ -129,6 +129,29 @@ int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t*
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream);
 int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream);
 
+/* ---- extended coordinates: what the Rust types hold --------------------------------------------------------
+ * `PublicKey::verify(&self, &Signature, BlsScalar)` receives `JubJubExtended` points (reference src/keys/public.rs:
+ * 114-118, src/signatures.rs:62-65) and normalises them itself with one field inversion per point
+ * (`to_hash_inputs()`, src/signatures.rs:127-128).  These entry points take every point as 96 bytes =
+ * U || V || Z (three canonical field elements; the affine point is (U/Z, V/Z); `get_u()/get_v()/get_z()` of the
+ * Rust type through `BlsScalar::to_bytes`) and normalise on the device with one inversion shared by many items,
+ * so a shim does no field arithmetic at all.  Scalars and m as everywhere else.  Same statuses; additionally a
+ * coordinate >= q gives 3 and Z = 0 (not a curve point in any representation) gives 1.  Argument order as the
+ * affine entry points. */
+int jjs_verify_single_ext_dev(const void* u, const void* R_ext, const void* PK_ext, const void* m, size_t n, void* status,
+                              void* tally, void* stream);
+int jjs_verify_double_ext_dev(const void* u, const void* R_ext, const void* R_prime_ext, const void* PK_ext,
+                              const void* PK_prime_ext, const void* m, size_t n, void* status, void* tally, void* stream);
+int jjs_verify_vargen_ext_dev(const void* u, const void* R_ext, const void* PK_ext, const void* Gen_ext, const void* m, size_t n,
+                              void* status, void* tally, void* stream);
+/* the same from host buffers, blocking */
+int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t* PK_ext, const uint8_t* m, size_t n,
+                          uint8_t* status, uint64_t tally[4]);
+int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t* R_prime_ext, const uint8_t* PK_ext,
+                          const uint8_t* PK_prime_ext, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]);
+int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t* PK_ext, const uint8_t* Gen_ext, const uint8_t* m,
+                          size_t n, uint8_t* status, uint64_t tally[4]);
+
 /* ---- multisignature: batch verify_share / combine (reference src/multisig.rs:284-387, 440-500) -------
  * Transcript t owns participants [offsets[t], offsets[t+1]) of the flattened device arrays z (N x 32),
  * PK, R, S (N x 64 affine); m is B x 32.  `offsets` is a HOST array of B + 1 entries starting at 0; every

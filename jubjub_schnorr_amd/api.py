@@ -95,11 +95,20 @@ class Engine:
 
     _WIDTHS = {"single": (32, 64, 64, 32), "double": (32, 64, 64, 64, 64, 32), "vargen": (32, 64, 64, 64, 32)}
 
-    def verify(self, scheme: str, *arrays, want_status: bool = True):
+    def verify_ext(self, scheme: str, *arrays, want_status: bool = True):
+        """Batch verify with every point in extended coordinates, (n, 96) = U || V || Z canonical (what the Rust
+        `JubJubExtended` holds; normalised on the device).  Same argument order and results as `verify`."""
+        return self.verify(scheme, *arrays, want_status=want_status, _ext=True)
+
+    def verify(self, scheme: str, *arrays, want_status: bool = True, _ext: bool = False):
         """Batch verify.  Argument order per scheme: single (u, R, PK, m); double (u, R, R', PK, PK', m);
         vargen (u, R, PK, Gen, m).  Returns (status, tally): same kind as the inputs (torch CUDA
         tensors, asynchronous on the current stream, or numpy arrays, blocking)."""
         widths = self._WIDTHS[scheme]
+        suffix = ""
+        if _ext:
+            widths = tuple(96 if w == 64 else w for w in widths)
+            suffix = "_ext"
         if len(arrays) != len(widths):
             raise ValueError(f"{scheme} verify takes {len(widths)} arrays")
         if _is_torch(arrays[0]):
@@ -109,9 +118,9 @@ class Engine:
             dev = arrays[0].device
             status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)[:n] if want_status else None
             tally = torch.zeros(4, dtype=torch.int64, device=dev)
-            fn = getattr(self._lib, f"jjs_verify_{scheme}_dev")
+            fn = getattr(self._lib, f"jjs_verify_{scheme}{suffix}_dev")
             _ffi.check(fn(*ptrs, n, ctypes.c_void_p(status.data_ptr()) if want_status and n else None,
-                          ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}_dev")
+                          ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}{suffix}_dev")
             return status, tally
         host = [self._host(a, w) for a, w in zip(arrays, widths)]
         n = host[0].shape[0]
@@ -119,9 +128,9 @@ class Engine:
             raise ValueError("all arrays must have the same number of items")
         status = np.empty(n, np.uint8)
         tally = np.zeros(4, np.uint64)
-        fn = getattr(self._lib, f"jjs_verify_{scheme}")
+        fn = getattr(self._lib, f"jjs_verify_{scheme}{suffix}")
         _ffi.check(fn(*[h.ctypes.data_as(ctypes.c_void_p) for h in host], n, status.ctypes.data_as(ctypes.c_void_p),
-                      tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}")
+                      tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}{suffix}")
         return status, tally
 
     _WIRE_WIDTHS = {"single": (64, 32, 32), "double": (96, 64, 32), "vargen": (64, 64, 32)}

@@ -21,6 +21,7 @@
 #include "../../include/jjs_gpu.h"
 #include "schemes.h"
 #include "decode.h"
+#include "normalize.h"
 #include "sign_core.h"
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
         if (P.bad && !all_ok) P.bad[item] = 1;
         if (P.ok) P.ok[item] = all_ok ? 1 : 0;
     }
+}
+// (U, V, Z) -> affine for the *_ext entry points: every lane owns the items lane, lane + lanes, ... and shares one
+// field inversion among them (normalize.h)
+__global__ __launch_bounds__(BLOCK) void normalize_kernel(normalize_params P) {
+    normalize_lane(P, (uint64_t)blockIdx.x * BLOCK + threadIdx.x, (uint64_t)gridDim.x * BLOCK);
 }
 __global__ __launch_bounds__(BLOCK) void compress_kernel(const uint8_t* affine, uint64_t n, uint8_t* out) {
     uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -859,12 +865,13 @@ static int ensure_wire(size_t n) {
         g->wire = nullptr; g->wire_items = 0;
     }
     size_t cap = n < 4096 ? 4096 : n;
-    HIP_TRY(hipMalloc(&g->wire, cap * (4 * 64 + 16)));
+    HIP_TRY(hipMalloc(&g->wire, cap * (4 * 64 + 16 + 48)));
     g->wire_items = cap;
     return JJS_OK;
 }
 static uint8_t* wire_pts(int k) { return g->wire + (size_t)k * g->wire_items * 64; }
 static uint8_t* wire_bad() { return g->wire + (size_t)4 * g->wire_items * 64; }
+static uint32_t* wire_scratch() { return reinterpret_cast<uint32_t*>(g->wire + (size_t)g->wire_items * (4 * 64 + 16)); }
 
 static int launch_decode(decode_params D, hipStream_t s) {
     D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
@@ -974,6 +981,126 @@ int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t*
 int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
     return wire_host(wire_vargen_locked, sig, 64, pk, 64, m, n, status, tally);
 }
+
+// ---- extended coordinates (U, V, Z): normalised on the device, then the same verify kernels -----------------
+static int launch_normalize(normalize_params N, hipStream_t s) {
+    N.bad = wire_bad();
+    N.scratch = wire_scratch();
+    // ~8 items per lane at BASELINE sizes (one inversion amortised over them), one item per lane for small calls
+    size_t blocks = (N.n + BLOCK - 1) / BLOCK, by_share = (N.n + (size_t)BLOCK * 32 - 1) / ((size_t)BLOCK * 32);
+    if (blocks > 512) blocks = 512;
+    if (blocks < by_share) blocks = by_share;
+    HIP_TRY(hipMemsetAsync(wire_bad(), 0, N.n, s));
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, N);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+static fe_src ext_src(const void* p) { return fe_src{(const uint8_t*)p, 96, 0}; }
+
+static int ext_single_locked(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
+                             void* stream) {
+    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
+    normalize_params N{};
+    N.n_src = 2; N.n = n;
+    N.src[0] = ext_src(R);  N.out[0] = wire_pts(0);
+    N.src[1] = ext_src(PK); N.out[1] = wire_pts(1);
+    if (int rc = launch_normalize(N, s)) return rc;
+    if (int rc = end_shared(s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    verify_params P = params_single((const uint8_t*)u, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+static int ext_double_locked(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                             size_t n, void* status, void* tally, void* stream) {
+    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
+    normalize_params N{};
+    N.n_src = 4; N.n = n;
+    N.src[0] = ext_src(R);   N.out[0] = wire_pts(0);
+    N.src[1] = ext_src(Rp);  N.out[1] = wire_pts(1);
+    N.src[2] = ext_src(PK);  N.out[2] = wire_pts(2);
+    N.src[3] = ext_src(PKp); N.out[3] = wire_pts(3);
+    if (int rc = launch_normalize(N, s)) return rc;
+    if (int rc = end_shared(s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    verify_params P = params_double((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3), (const uint8_t*)m, n,
+                                    g->tag, g->comb_g, g->comb_gn, o);
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+static int ext_vargen_locked(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* status,
+                             void* tally, void* stream) {
+    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    if (int rc = ensure_wire(n)) return rc;
+    if (int rc = begin_shared(s)) return rc;
+    normalize_params N{};
+    N.n_src = 3; N.n = n;
+    N.src[0] = ext_src(R);   N.out[0] = wire_pts(0);
+    N.src[1] = ext_src(PK);  N.out[1] = wire_pts(1);
+    N.src[2] = ext_src(Gen); N.out[2] = wire_pts(2);
+    if (int rc = launch_normalize(N, s)) return rc;
+    if (int rc = end_shared(s)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    verify_params P = params_vargen((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
+    P.pre_malformed = wire_bad();
+    return verify_dev_common(P, status, tally, s);
+}
+int jjs_verify_single_ext_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
+                              void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    return ext_single_locked(u, R, PK, m, n, status, tally, stream);
+}
+int jjs_verify_double_ext_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                              size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    return ext_double_locked(u, R, Rp, PK, PKp, m, n, status, tally, stream);
+}
+int jjs_verify_vargen_ext_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                              void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    return ext_vargen_locked(u, R, PK, Gen, m, n, status, tally, stream);
+}
+int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n, uint8_t* status,
+                          uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    const host_col cols[] = {{u, 32}, {R, 96}, {PK, 96}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        return ext_single_locked(d[0], d[1], d[2], d[3], nl, st, tl, s);
+    });
+}
+int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                          const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    const host_col cols[] = {{u, 32}, {R, 96}, {Rp, 96}, {PK, 96}, {PKp, 96}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        return ext_double_locked(d[0], d[1], d[2], d[3], d[4], d[5], nl, st, tl, s);
+    });
+}
+int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m, size_t n,
+                          uint8_t* status, uint64_t tally[4]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    const host_col cols[] = {{u, 32}, {R, 96}, {PK, 96}, {Gen, 96}, {m, 32}};
+    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
+        return ext_vargen_locked(d[0], d[1], d[2], d[3], d[4], nl, st, tl, s);
+    });
+}
+
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;

@@ -252,3 +252,20 @@ def torsion_grid(scheme: str, seed: int = 77, extra: int = 0, reps: int = 6):
         for key in rows:
             rows[key].append(vals[key])
     return {key: np.stack(v) for key, v in rows.items()}
+
+
+def to_extended(points: np.ndarray, rng: np.random.Generator, z_one_every: int = 7) -> np.ndarray:
+    """Affine (n, 64) -> extended (n, 96) = U || V || Z with a random non-zero Z per point (Z = 1 for every
+    `z_one_every`-th): the same projective point the Rust type could hold after any chain of additions."""
+    out = np.empty((len(points), 96), np.uint8)
+    for i, row in enumerate(points):
+        u, v = to_pt(row)
+        z = 1 if (z_one_every and i % z_one_every == 0) else int.from_bytes(rng.bytes(40), "little") % (o.Q - 1) + 1
+        out[i, :32] = fe_bytes(u * z % o.Q); out[i, 32:64] = fe_bytes(v * z % o.Q); out[i, 64:] = fe_bytes(z)
+    return out
+
+
+def batch_to_extended(scheme: str, b: dict, seed: int = 3) -> list:
+    """The arrays of a batch in ABI order with every point array turned into extended coordinates."""
+    rng = np.random.default_rng(seed)
+    return [to_extended(b[k], rng) if b[k].shape[1] == 64 else b[k] for k in ARG_ORDER[scheme]]

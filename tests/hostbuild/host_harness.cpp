@@ -6,6 +6,7 @@
 #include <vector>
 #include "schemes.h"
 #include "decode.h"
+#include "normalize.h"
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
 
@@ -162,6 +163,16 @@ int jjs_host_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) 
         memcpy(out + 64 * i, d.u.w, 32); memcpy(out + 64 * i + 32, d.v.w, 32);
         ok[i] = d.ok ? 1 : 0;
     }
+    return 0;
+}
+// extended points (k arrays of n x 96) -> affine (k arrays of n x 64) + malformed flags, run as `lanes` lanes
+int jjs_host_normalize(const uint8_t* const* ext, int k, size_t n, size_t lanes, uint8_t* const* out, uint8_t* bad) {
+    std::vector<uint32_t> scratch(9 * n + 16);
+    normalize_params P{};
+    P.n_src = (uint32_t)k; P.n = n; P.bad = bad; P.scratch = scratch.data();
+    for (int i = 0; i < k; ++i) { P.src[i] = fe_src{ext[i], 96, 0}; P.out[i] = out[i]; }
+    memset(bad, 0, n);
+    for (size_t lane = 0; lane < lanes; ++lane) normalize_lane(P, lane, lanes);
     return 0;
 }
 int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, const uint8_t* S, const uint8_t* m,

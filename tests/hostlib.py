@@ -132,3 +132,15 @@ def raw_sqr(a):
 def raw_dot5(t, row):
     t = _u32(t); n = len(t); d = np.empty((n, 9), np.uint32); s = np.empty((n, 9), np.uint32)
     load().jjs_host_raw_dot5(_p(t), row, ctypes.c_size_t(n), _p(d), _p(s)); return d, s
+
+
+def normalize(ext_arrays, lanes=1):
+    """extended (n, 96) arrays -> affine (n, 64) arrays + malformed flags, through csrc/normalize.h on the CPU."""
+    ext = [np.ascontiguousarray(a, dtype=np.uint8) for a in ext_arrays]
+    n, k = len(ext[0]), len(ext)
+    outs = [np.zeros((n, 64), np.uint8) for _ in ext]
+    bad = np.zeros(n, np.uint8)
+    PP = ctypes.c_void_p * k
+    load().jjs_host_normalize(PP(*[a.ctypes.data for a in ext]), k, ctypes.c_size_t(n), ctypes.c_size_t(lanes),
+                              PP(*[a.ctypes.data for a in outs]), _p(bad))
+    return outs, bad

@@ -34,7 +34,15 @@ def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
     tors = pt_arr([o.mul(t8, k) for k in range(1, 8)])
     rng = np.random.default_rng(99)
     info = bench.host_info()
-    threads = max(1, min(info["affinity_cores"], oc.max_threads(native)))
+    probe = {k: v[:4096] for k, v in bench.make_inputs(eng, "single", 4096, 0)[0].items()}
+    probe = [probe[k].cpu().numpy() for k in ARG_ORDER["single"]]
+
+    def probe_rate(t):
+        t0 = time.time()
+        oc.verify_single(*probe, threads=t, native=native)
+        return 4096 / (time.time() - t0)
+
+    threads, _, _ = bench.pick_threads(probe_rate, info, oc.max_threads(native))
     report = {"items_per_scheme": n, "csrc_sha256": bench.csrc_hash(), "oracle": "oracle/jjs_oracle.c", "host": info,
               "oracle_threads": threads, "schemes": {}}
     for scheme in schemes:

@@ -48,3 +48,13 @@ def test_committed_pmc_counters_are_only_quoted_for_the_code_they_were_measured_
 def test_host_info_names_the_cpu():
     info = bench.host_info()
     assert info["nproc"] >= info["affinity_cores"] >= 1 and "cpu_model" in info
+
+
+def test_thread_choice_prefers_the_fastest_probe():
+    info = {"affinity_cores": 256, "cgroup_cpu_quota_cores": None}
+    rates = {128: 17000.0, 64: 19000.0, 32: 21000.0, 16: 21700.0, 8: 11000.0}
+    t, r, seen = bench.pick_threads(lambda k: rates[k], info, 128)
+    assert (t, r) == (16, 21700.0) and sorted(seen) == [8, 16, 32, 64, 128]
+    info = {"affinity_cores": 256, "cgroup_cpu_quota_cores": 16.0}
+    t, _, seen = bench.pick_threads(lambda k: 1000.0 * k, info, 128)
+    assert t == 16 and max(seen) == 16

@@ -8,7 +8,7 @@ import pytest
 
 import jjs_oracle as o
 import jjs_oracle_c as oc
-from helpers import (ARG_ORDER, edge_cases, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
+from helpers import (ARG_ORDER, batch_to_extended, edge_cases, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
                      torsion_grid)
 
 pytestmark = pytest.mark.gpu
@@ -274,6 +274,91 @@ def test_public_key_derivation(eng, reference_kat):
     assert bytes(comp[0]) + bytes(comp[1]) == serde.b58decode(v["serde_public_key_double"])
     PK1, bad1 = eng.public_keys(dev(sk))
     assert torch.equal(PK1.cpu(), torch.from_numpy(PK)) and host(bad1).tolist() == bad.tolist()
+
+
+# ---- extended coordinates: what `PublicKey::verify` receives (reference src/keys/public.rs:114-118) ----------
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+@pytest.mark.parametrize("n", [1, 65, 1000])
+def test_verify_ext_matches_affine(eng, scheme, n):
+    """Every point handed over as (U, V, Z) with a random Z: same statuses and tally as the oracle gives for the
+    affine points; device-pointer and host-buffer entry points."""
+    b = make_batch(scheme, n, seed=500 + n, n_keys=16)
+    want = oracle_verify(scheme, b)
+    ext = batch_to_extended(scheme, b, seed=n)
+    st, tally = eng.verify_ext(scheme, *[dev(a) for a in ext])
+    assert host(st).tolist() == want.tolist()
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    st_h, tally_h = eng.verify_ext(scheme, *ext)
+    assert st_h.tolist() == want.tolist() and tally_h.tolist() == host(tally).tolist()
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_verify_ext_edge_cases(eng, scheme):
+    """The adversarial items of the affine tests (small-order, off-curve, non-canonical ...) in extended form, plus
+    what only this format can express: Z = 0 (InvalidPoint) and coordinates >= q (Malformed)."""
+    b = edge_cases(scheme)
+    want = oracle_verify(scheme, b).copy()
+    ext = batch_to_extended(scheme, b, seed=9)
+    names = ARG_ORDER[scheme]
+    pts = [i for i, k in enumerate(names) if b[k].shape[1] == 64]
+    # non-canonical affine coordinates cannot be rescaled: keep them verbatim with Z = 1 (still Malformed)
+    for i in pts:
+        raw = b[names[i]]
+        big = np.array([to_int(r[:32]) >= o.Q or to_int(r[32:]) >= o.Q for r in raw])
+        ext[i][big, :64] = raw[big]; ext[i][big, 64:] = fe_bytes(1)
+    # valid item 0 repeated with Z = 0 on one point at a time, then with Z = q, then with U = q
+    extra = []
+    for i in pts:
+        for kind in ("z0", "zq", "uq"):
+            row = [a[0:1].copy() for a in ext]
+            if kind == "z0":
+                row[i][0, 64:] = 0
+            elif kind == "zq":
+                row[i][0, 64:] = fe_bytes(o.Q)
+            else:
+                row[i][0, :32] = fe_bytes(o.Q)
+            extra.append((row, 1 if kind == "z0" else 3))
+    assert want[0] == 0
+    arrays = [np.concatenate([ext[j]] + [row[j] for row, _ in extra]) for j in range(len(ext))]
+    want = np.concatenate([want, np.array([w for _, w in extra], np.uint8)])
+    st, tally = eng.verify_ext(scheme, *[dev(a) for a in arrays])
+    assert host(st).tolist() == want.tolist()
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+
+
+def test_verify_ext_golden_vectors(eng):
+    """The reference-held vectors (multisig KAT signature, serde signatures, legacy-double attack fixture) with
+    their points rescaled by random Z."""
+    from helpers import to_extended
+    vec = json.load(open(os.path.join(GOLDEN, "verify_vectors.json")))
+    H = lambda x: np.frombuffer(bytes.fromhex(x), np.uint8)  # noqa: E731
+    rng = np.random.default_rng(2321)
+    for scheme, items in vec.items():
+        arrays = [np.stack([H(v[k]) for v in items]) for k in ARG_ORDER[scheme]]
+        canonical = np.array([v["status"] != 3 for v in items])
+        ext = [to_extended(a[canonical], rng, z_one_every=0) if a.shape[1] == 64 else a[canonical] for a in arrays]
+        st, _ = eng.verify_ext(scheme, *ext)
+        assert st.tolist() == [v["status"] for v in items if v["status"] != 3], scheme
+
+
+@pytest.mark.parametrize("scheme", ["single", "double"])
+def test_verify_ext_full_size(eng, scheme):
+    """2^20 items in extended form built on the device (Z = a per-item value, U = u*Z, V = v*Z through the field
+    multiplier): statuses known by construction, several items per lane share one inversion."""
+    import torch
+    import bench
+    n = 1 << 20
+    arrays, expect = bench.make_inputs(eng, scheme, n, 0)
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    def to_ext(pts):
+        z = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen); z[:, 31] &= 0x3F; z[:, 0] |= 1
+        z = z.cuda()
+        U = eng.debug_fq_mul(pts[:, :32].contiguous(), z); V = eng.debug_fq_mul(pts[:, 32:].contiguous(), z)
+        return torch.cat([U, V, z], 1).contiguous()
+    call = [to_ext(arrays[k]) if arrays[k].shape[1] == 64 else arrays[k] for k in ARG_ORDER[scheme]]
+    st, tally = eng.verify_ext(scheme, *call)
+    assert torch.equal(st, expect)
+    assert host(tally).tolist() == [int((expect == k).sum()) for k in range(4)]
 
 
 # ---- wire formats (SURVEY.md 8f-2) ---------------------------------------------------------------------

@@ -308,3 +308,28 @@ def test_golden_vectors_on_the_host_build():
         st, _, c = hl.verify(scheme, b, want_c=True)
         assert st.tolist() == [v["status"] for v in items], scheme
         assert [r.tobytes().hex() for r in c] == [v["c"] for v in items], scheme
+
+
+# ---- extended-coordinate inputs (csrc/normalize.h) --------------------------------------------------------
+def test_normalize_extended_points():
+    """(U, V, Z) -> (U/Z, V/Z) with one inversion per lane: any lane count, ragged item counts, 2..4 points per
+    item; Z = 0 gives the off-curve marker (0, 0); a coordinate >= q flags the item."""
+    from helpers import to_extended
+    rng = np.random.default_rng(17)
+    for k, n, lanes in ((2, 1, 1), (2, 37, 1), (3, 37, 5), (4, 64, 64), (4, 50, 200), (2, 300, 7)):
+        aff = [pt_arr([o.mul(o.G, int.from_bytes(rng.bytes(20), "little") + 1) for _ in range(n)]) for _ in range(k)]
+        ext = [to_extended(a, rng) for a in aff]
+        zero_rows, bad_rows = set(), set()
+        if n > 8:
+            ext[0][3, 64:] = 0; zero_rows.add((0, 3))                      # Z = 0
+            ext[k - 1][5, 64:] = 0; zero_rows.add((k - 1, 5))
+            ext[0][6, 64:] = fe_bytes(o.Q); bad_rows.add(6)                 # Z = q: not canonical
+            ext[k - 1][7, :32] = 0xFF; bad_rows.add(7)                      # U = 2^256 - 1
+        outs, bad = hl.normalize(ext, lanes)
+        assert set(np.nonzero(bad)[0].tolist()) == bad_rows
+        for j in range(k):
+            for i in range(n):
+                if i in bad_rows:
+                    continue
+                want = bytes(64) if (j, i) in zero_rows else aff[j][i].tobytes()
+                assert outs[j][i].tobytes() == want, (k, n, lanes, j, i)
