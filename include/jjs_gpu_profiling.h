@@ -16,6 +16,9 @@ extern "C" {
 /* Ablations (results become meaningless): skip phases of the verify kernels in later launches; bit0 = point
  * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars); 0 restores the full path. */
 int jjs_debug_skip_phases(unsigned mask);
+/* Path selection for A/B timing (results stay exact): 0 = by batch size (product behaviour), 1 = always the
+ * throughput path, 2 = the latency path for every single / double call of at most 16 384 items. */
+int jjs_debug_force_path(int which);
 /* Test mode for boxes with one GPU: a later jjs_init(k) with k above the visible device count creates k logical
  * devices (own stream, tables, workspace, staging each) that share the visible cards round-robin; the tallies are
  * then summed on the host, since two ranks on one card cannot form an RCCL clique. */

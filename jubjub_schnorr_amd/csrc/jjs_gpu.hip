@@ -22,6 +22,7 @@
 #include "schemes.h"
 #include "decode.h"
 #include "normalize.h"
+#include "small_batch.h"
 #include "sign_core.h"
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
@@ -98,6 +99,72 @@ __global__ __launch_bounds__(BLOCK) void resolve_kernel(verify_params P) {
                 unsigned long long b = __ballot(writer && st == k);
                 if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
             }
+        }
+    }
+}
+
+// ---- latency path for small batches (small_batch.h) ------------------------------------------------------
+// Phase A: the three roles share one launch; the role of a block follows from its index, the longest-running
+// blocks first (hash, then the chains from the far position down, then the point checks).
+__global__ __launch_bounds__(BLOCK, 2) void small_a_kernel(small_params S, uint32_t hash_blocks, uint32_t chain_blocks_per_pos) {
+    const uint32_t b = blockIdx.x;
+    const uint64_t n = S.V.n;
+    if (b < hash_blocks) {
+        __builtin_amdgcn_s_setprio(3);            // the critical path: ahead of co-resident chain / point waves
+        const uint64_t item = (uint64_t)b * BLOCK + threadIdx.x;
+        if (item < n) sb_hash_item(S, item);
+        return;
+    }
+    const uint32_t cb = b - hash_blocks;
+    if (cb < SB_POSITIONS * chain_blocks_per_pos) {
+        const uint32_t k = SB_POSITIONS - 1 - cb / chain_blocks_per_pos;           // block-uniform position
+        const uint64_t r = (uint64_t)(cb % chain_blocks_per_pos) * BLOCK + threadIdx.x;
+        const uint32_t per_item = 2 * S.V.n_eq;                                     // (equation, PK | R)
+        if (r < n * per_item) sb_chain_lane(S, r / per_item, (uint32_t)(r % per_item) >> 1, (uint32_t)r & 1u, k);
+        return;
+    }
+    const uint64_t r = (uint64_t)(cb - SB_POSITIONS * chain_blocks_per_pos) * BLOCK + threadIdx.x;
+    if (r < n * S.V.n_points) sb_point_lane(S, r / S.V.n_points, (uint32_t)(r % S.V.n_points));
+}
+
+// lane ^ 1 and lane ^ 2 inside a group of four lanes: one DPP move per word
+template <int CTRL>
+__device__ __forceinline__ ext_pt dpp_quad(const ext_pt& p) {
+    ext_pt r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.x.l[i], CTRL, 0xf, 0xf, false);
+        r.y.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.y.l[i], CTRL, 0xf, 0xf, false);
+        r.z.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.z.l[i], CTRL, 0xf, 0xf, false);
+        r.t.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.t.l[i], CTRL, 0xf, 0xf, false);
+    }
+    return r;
+}
+// Phase B: four adjacent lanes per equation (eight per item for the double scheme); every lane of a group ends
+// with the whole left side of its equation, lane 0 of the item writes the verdict.
+__global__ __launch_bounds__(BLOCK, 2) void small_b_kernel(small_params S) {
+    const uint64_t n = S.V.n;
+    const uint32_t lanes_per_item = SB_POSITIONS * S.V.n_eq;
+    const uint64_t total = n * lanes_per_item;
+    const uint64_t idx = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = idx < total;              // groups are whole: total is a multiple of the group size
+    const uint64_t ii = active ? idx : total - 1;
+    const uint64_t item = ii / lanes_per_item;
+    const uint32_t sub = (uint32_t)(ii % lanes_per_item), e = sub >> 2, k = sub & 3u;
+    const prep_record r = load_prep(S.V.prep, n, item);
+    ext_pt acc = sb_piece(S, item, e, k, r);
+    acc = sb_add(acc, dpp_quad<0xB1>(acc));       // quad_perm [1,0,3,2]: partner lane ^ 1
+    acc = sb_add(acc, dpp_quad<0x4E>(acc));       // quad_perm [2,3,0,1]: partner lane ^ 2
+    bool eq_ok = ext_is_identity(acc);
+    if (S.V.n_eq == 2) eq_ok = (__shfl_xor((int)eq_ok, 4) != 0) && eq_ok;
+    const uint32_t st = sb_status(r.malformed, sb_points_ok(S, item), eq_ok);
+    const bool writer = active && sub == 0;
+    if (writer && S.V.status) S.V.status[item] = (uint8_t)st;
+    if (S.V.tally) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            unsigned long long bal = __ballot(writer && st == c);
+            if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&S.V.tally[c], (unsigned long long)__popcll(bal));
         }
     }
 }
@@ -242,29 +309,47 @@ __global__ __launch_bounds__(BLOCK) void dbg_half_scalars_kernel(const uint8_t* 
 
 // ---------------------------------------------------------------------------------------------
 // Per-device state: everything a launch on that device needs (tables, per-lane workspace, scratch).
+// What one verification call in flight needs beside its inputs.  A device has one big slot (slot 0: the workspace
+// of the persistent verify grid, used by every large call and by the signer / multisig kernels) and
+// N_SMALL_SLOTS small ones, handed out round-robin to calls of at most SMALL_SLOT_ITEMS items: calls in different
+// slots touch disjoint buffers and are not ordered against each other, so small calls issued on different
+// streams overlap on the device; calls that share a slot are ordered by its event.
+struct call_slot {
+    uint32_t* workspace = nullptr;    // WS_WORDS_PER_LANE words per lane of the verify grid
+    int grid_verify = 0;              // blocks of verify_kernel that fit this workspace
+    uint64_t* pending = nullptr;      // queue of the resolve pass: [0] = count, then one entry per queued item
+    size_t pending_items = 0;
+    uint8_t* prep = nullptr;          // prepare_kernel -> verify_kernel records, 65 bytes per item (grow-only)
+    size_t prep_items = 0;
+    uint8_t* wire = nullptr;          // decoded / normalised points (4 x n x 64), flags, scratch: wire and ext entry points
+    size_t wire_items = 0;
+    uint8_t* small = nullptr;         // latency path: window tables of the chain lanes + per-point verdicts (grow-only)
+    size_t small_bytes = 0;
+    hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
+};
+constexpr int N_SMALL_SLOTS = 3;
+constexpr size_t SMALL_SLOT_ITEMS = 16384;
+// largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
+// path is faster (tools/batch_size_curve.py)
+constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 8192};
+
 struct device_state {
     int device = -1;               // HIP device ordinal
+    call_slot slots[1 + N_SMALL_SLOTS];
+    unsigned next_small = 0;
     hipStream_t stream = nullptr;  // used by the host-buffer entry points
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
     uint8_t* tag = nullptr;
-    uint32_t* workspace = nullptr;
     unsigned long long* tally = nullptr;
-    int grid_verify = 0, grid_sign = 0, grid_resolve = 0, grid_prepare = 0;
-    size_t ws_lanes = 0;
-    hipEvent_t last_use = nullptr;  // end of the last launch that used the shared workspaces
+    int grid_sign = 0, grid_resolve = 0, grid_prepare = 0;
+    hipEvent_t last_use = nullptr;  // host-buffer calls: end of the last use of the staging arena and the counters
     uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
     uint8_t* dlog_hash = nullptr;
     uint32_t* tags_long = nullptr; // SAFE tags for long transcripts (multisig)
     uint8_t* msig = nullptr;       // multisig scratch
     size_t msig_items = 0, msig_transcripts = 0;
     int grid_msig = 0;
-    uint8_t* wire = nullptr;       // decoded points (4 x n x 64) + flags (n) for the *_wire entry points
-    size_t wire_items = 0;
-    uint64_t* pending = nullptr;   // queue of the resolve pass: [0] = count, then one entry per queued item
-    size_t pending_items = 0;
-    uint8_t* prep = nullptr;       // prepare_kernel -> verify_kernel records, 65 bytes per item (grow-only)
-    size_t prep_items = 0;
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
@@ -298,6 +383,7 @@ library_state L;
 // Device bound to the work in progress on THIS host thread: set by check_ready for an entry point and by each
 // per-device worker of run_host for its own block (the workers run concurrently, one device each).
 thread_local device_state* g = nullptr;
+thread_local call_slot* sl = nullptr;      // slot of the call in progress on this thread (pick_slot)
 
 // One message buffer per host thread: jjs_last_error() describes the calling thread's last failure and a
 // pointer it returned is never written by another thread.
@@ -332,62 +418,116 @@ int grid_for(int resident, size_t n) {
 #if defined(JJS_PROFILING)
 uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_prof.so only)
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
+int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
 #endif
 
-// The per-lane workspace, the wire and the multisig scratch are shared by every call, so launches issued
-// on different streams are ordered one after the other on the device: each waits for the previous user.
+// Small calls take the small slots in turn, everything else the big one (see call_slot).
+void pick_slot(size_t n) {
+    if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
+    else sl = &g->slots[0];
+}
+void big_slot() { sl = &g->slots[0]; }
+// Launches that use one slot are ordered one after the other on the device, also across streams: each waits
+// for the slot's previous user.
 int begin_shared(hipStream_t s) {
-    HIP_TRY(hipStreamWaitEvent(s, g->last_use, 0));
+    HIP_TRY(hipStreamWaitEvent(s, sl->last_use, 0));
     return JJS_OK;
 }
 int end_shared(hipStream_t s) {
-    HIP_TRY(hipEventRecord(g->last_use, s));
+    HIP_TRY(hipEventRecord(sl->last_use, s));
     return JJS_OK;
 }
 
 int ensure_pending(size_t n) {
-    if (n <= g->pending_items) return JJS_OK;
-    if (g->pending) {
+    if (n <= sl->pending_items) return JJS_OK;
+    if (sl->pending) {
         HIP_TRY(hipDeviceSynchronize());        // earlier launches may still use the old queue
-        HIP_TRY(hipFree(g->pending));
-        g->pending = nullptr; g->pending_items = 0;
+        HIP_TRY(hipFree(sl->pending));
+        sl->pending = nullptr; sl->pending_items = 0;
     }
-    size_t cap = n < 65536 ? 65536 : n;
-    HIP_TRY(hipMalloc(&g->pending, (cap + 2) * sizeof(uint64_t)));
-    g->pending_items = cap;
+    size_t cap = n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n;
+    HIP_TRY(hipMalloc(&sl->pending, (cap + 2) * sizeof(uint64_t)));
+    sl->pending_items = cap;
     return JJS_OK;
 }
 
 int ensure_prep(size_t n) {
-    if (n <= g->prep_items) return JJS_OK;
-    if (g->prep) {
+    if (n <= sl->prep_items) return JJS_OK;
+    if (sl->prep) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(g->prep));
-        g->prep = nullptr; g->prep_items = 0;
+        HIP_TRY(hipFree(sl->prep));
+        sl->prep = nullptr; sl->prep_items = 0;
     }
-    size_t cap = n < 65536 ? 65536 : n;
-    HIP_TRY(hipMalloc(&g->prep, cap * 65 + 64));
-    g->prep_items = cap;
+    size_t cap = n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n;
+    HIP_TRY(hipMalloc(&sl->prep, cap * 65 + 64));
+    sl->prep_items = cap;
     return JJS_OK;
 }
 
-// Three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy), verify (the
-// equations; register-bound) and the resolve pass over the items verify queued (normally the invalid ones
-// only; the grid is sized for the batch, lanes without a queue entry leave at once).
+int ensure_small(size_t bytes) {
+    if (bytes <= sl->small_bytes) return JJS_OK;
+    if (sl->small) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(sl->small));
+        sl->small = nullptr; sl->small_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&sl->small, bytes));
+    sl->small_bytes = bytes;
+    return JJS_OK;
+}
+
+// Latency path (small_batch.h): two launches, every signature spread over 11 (single) or 21 (double) lanes.
+int launch_small(verify_params P, hipStream_t s) {
+    const size_t table_bytes = P.n * sb_table_words_per_item(P.n_eq) * sizeof(uint32_t);
+    if (int rc = ensure_small(table_bytes + 4 * P.n + 64)) return rc;
+    small_params S{};
+    P.small_mode = 1;
+    S.V = P;
+    S.tables = reinterpret_cast<uint32_t*>(sl->small);
+    S.point_ok = sl->small + table_bytes;
+    const unsigned hash_blocks = (unsigned)((P.n + BLOCK - 1) / BLOCK);
+    const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
+    const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + SB_POSITIONS * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,
+                       (uint32_t)hash_blocks, (uint32_t)chain_blocks);
+    hipLaunchKernelGGL(small_b_kernel, dim3((unsigned)((P.n * P.n_eq * SB_POSITIONS + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+bool small_path_applies(const verify_params& P) {
+    if (P.n_eq < 1 || P.n_eq > 2) return false;
+    for (uint32_t k = 0; k < P.n_eq; ++k)
+        if (!P.eq[k].comb) return false;               // fixed-generator equations only (single, double)
+#if defined(JJS_PROFILING)
+    if (g_force_path == 1) return false;
+    if (g_force_path == 2) return P.n <= SMALL_SLOT_ITEMS;
+#endif
+    return P.n <= SMALL_PATH_MAX_ITEMS[P.n_eq];
+}
+
+// Throughput path, three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy),
+// verify (the equations; register-bound) and the resolve pass over the items verify queued (normally the invalid
+// ones only; the grid is sized for the batch, lanes without a queue entry leave at once).  Small batches of the
+// fixed-generator schemes take the latency path instead.  The slot has been chosen by the caller (pick_slot).
 int launch_verify(verify_params P, hipStream_t s) {
     if (P.n == 0) return JJS_OK;
 #if defined(JJS_PROFILING)
     P.skip_phases = g_skip_phases;
 #endif
-    if (int rc = ensure_pending(P.n)) return rc;
     if (int rc = ensure_prep(P.n)) return rc;
-    P.prep = g->prep;
-    P.pending_count = reinterpret_cast<unsigned long long*>(g->pending);
-    P.pending = g->pending + 2;
+    P.prep = sl->prep;
+    P.workspace = sl->workspace;
     if (int rc = begin_shared(s)) return rc;
-    HIP_TRY(hipMemsetAsync(g->pending, 0, sizeof(uint64_t), s));
+    if (small_path_applies(P)) {
+        if (int rc = launch_small(P, s)) return rc;
+        return end_shared(s);
+    }
+    if (int rc = ensure_pending(P.n)) return rc;
+    P.pending_count = reinterpret_cast<unsigned long long*>(sl->pending);
+    P.pending = sl->pending + 2;
+    HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
     hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P);
-    hipLaunchKernelGGL(verify_kernel, dim3(grid_for(g->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
+    hipLaunchKernelGGL(verify_kernel, dim3(grid_for(sl->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(g->grid_resolve, P.n * P.resolve_lanes)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
     return end_shared(s);
@@ -441,13 +581,21 @@ int init_device(device_state& d, int ordinal) {
     if (per_cu_v < 1) per_cu_v = 1;
     if (per_cu_s < 1) per_cu_s = 1;
     if (per_cu_m < 1) per_cu_m = 1;
-    d.grid_verify = prop.multiProcessorCount * per_cu_v;
     d.grid_sign = prop.multiProcessorCount * per_cu_s;
     d.grid_msig = prop.multiProcessorCount * per_cu_m;
-    int lanes_blocks = d.grid_verify > d.grid_sign ? d.grid_verify : d.grid_sign;
+    // slot 0: the workspace of the largest persistent grid (verify, sign, multisig share it); small slots: one
+    // lane's worth per item of the largest call they take
+    d.slots[0].grid_verify = prop.multiProcessorCount * per_cu_v;
+    int lanes_blocks = d.slots[0].grid_verify > d.grid_sign ? d.slots[0].grid_verify : d.grid_sign;
     if (d.grid_msig > lanes_blocks) lanes_blocks = d.grid_msig;
-    d.ws_lanes = (size_t)lanes_blocks * BLOCK;
-    HIP_TRY(hipMalloc(&d.workspace, d.ws_lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
+    for (int i = 0; i <= N_SMALL_SLOTS; ++i) {
+        call_slot& c = d.slots[i];
+        if (i > 0) c.grid_verify = (int)(SMALL_SLOT_ITEMS / BLOCK);
+        const size_t lanes = i == 0 ? (size_t)lanes_blocks * BLOCK : SMALL_SLOT_ITEMS;
+        HIP_TRY(hipMalloc(&c.workspace, lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
+        HIP_TRY(hipEventCreateWithFlags(&c.last_use, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.last_use, d.stream));
+    }
     HIP_TRY(hipMalloc(&d.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d.tag, 32));
@@ -471,10 +619,15 @@ void free_device(device_state& d) {
     if (d.device < 0) return;
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
-    void* bufs[] = {d.workspace, d.comb_g, d.comb_gn, d.tag, d.tally, d.wire, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash,
-                    d.pending, d.stage, d.prep};
+    void* bufs[] = {d.comb_g, d.comb_gn, d.tag, d.tally, d.msig, d.tags_long, d.dlog_pow, d.dlog_hash, d.stage};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (call_slot& c : d.slots) {
+        void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small};
+        for (void* b : sb)
+            if (b) (void)hipFree(b);
+        if (c.last_use) (void)hipEventDestroy(c.last_use);
+    }
     if (d.pinned) (void)hipHostFree(d.pinned);
     if (d.last_use) (void)hipEventDestroy(d.last_use);
     for (int i = 0; i < 33; ++i) {
@@ -787,49 +940,57 @@ int jjs_stream_sync(void* stream) {
     return JJS_OK;
 }
 
-// ---- device-buffer entry points --------------------------------------------------------------
+// ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
+static int affine_single_locked(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
+                                void* stream) {
+    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
+                                           g->comb_g, o), status, tally, (hipStream_t)stream);
+}
+static int affine_double_locked(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                                size_t n, void* status, void* tally, void* stream) {
+    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
+                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o),
+                             status, tally, (hipStream_t)stream);
+}
+static int affine_vargen_locked(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                                void* status, void* tally, void* stream) {
+    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
+                                           (const uint8_t*)m, n, o), status, tally, (hipStream_t)stream);
+}
 int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
                           void* tally, void* stream) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
-    return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
-                                           g->comb_g, o), status, tally, s);
+    return affine_single_locked(u, R, PK, m, n, status, tally, stream);
 }
 int jjs_verify_double_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
                           size_t n, void* status, void* tally, void* stream) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
-    return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
-                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o),
-                             status, tally, s);
+    return affine_double_locked(u, R, Rp, PK, PKp, m, n, status, tally, stream);
 }
 int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
                           void* status, void* tally, void* stream) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
-    return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
-                                           (const uint8_t*)m, n, o), status, tally, s);
+    return affine_vargen_locked(u, R, PK, Gen, m, n, status, tally, stream);
 }
-
-// ---- host-buffer entry points ----------------------------------------------------------------
 int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                       uint8_t* status, uint64_t tally[4]) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {m, 32}};
     return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
-        return verify_dev_common(params_single((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
-                                               (const uint8_t*)d[3], nl, g->comb_g, o), st, tl, (hipStream_t)s);
+        return affine_single_locked(d[0], d[1], d[2], d[3], nl, st, tl, s);
     });
 }
 int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
@@ -838,10 +999,7 @@ int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, con
     if (int rc = check_ready()) return rc;
     const host_col cols[] = {{u, 32}, {R, 64}, {Rp, 64}, {PK, 64}, {PKp, 64}, {m, 32}};
     return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
-        return verify_dev_common(params_double((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
-                                               (const uint8_t*)d[3], (const uint8_t*)d[4], (const uint8_t*)d[5], nl,
-                                               g->tag, g->comb_g, g->comb_gn, o), st, tl, (hipStream_t)s);
+        return affine_double_locked(d[0], d[1], d[2], d[3], d[4], d[5], nl, st, tl, s);
     });
 }
 int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
@@ -850,28 +1008,26 @@ int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, con
     if (int rc = check_ready()) return rc;
     const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {Gen, 64}, {m, 32}};
     return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        out_ptrs o{(uint8_t*)st, (unsigned long long*)tl, nullptr, g->workspace};
-        return verify_dev_common(params_vargen((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2],
-                                               (const uint8_t*)d[3], (const uint8_t*)d[4], nl, o), st, tl, (hipStream_t)s);
+        return affine_vargen_locked(d[0], d[1], d[2], d[3], d[4], nl, st, tl, s);
     });
 }
 
 // ---- wire formats: on-device decoding, then the same verify kernel -----------------------------------
 static int ensure_wire(size_t n) {
-    if (n <= g->wire_items) return JJS_OK;
-    if (g->wire) {
+    if (n <= sl->wire_items) return JJS_OK;
+    if (sl->wire) {
         HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old buffer
-        HIP_TRY(hipFree(g->wire));
-        g->wire = nullptr; g->wire_items = 0;
+        HIP_TRY(hipFree(sl->wire));
+        sl->wire = nullptr; sl->wire_items = 0;
     }
     size_t cap = n < 4096 ? 4096 : n;
-    HIP_TRY(hipMalloc(&g->wire, cap * (4 * 64 + 16 + 48)));
-    g->wire_items = cap;
+    HIP_TRY(hipMalloc(&sl->wire, cap * (4 * 64 + 16 + 48)));
+    sl->wire_items = cap;
     return JJS_OK;
 }
-static uint8_t* wire_pts(int k) { return g->wire + (size_t)k * g->wire_items * 64; }
-static uint8_t* wire_bad() { return g->wire + (size_t)4 * g->wire_items * 64; }
-static uint32_t* wire_scratch() { return reinterpret_cast<uint32_t*>(g->wire + (size_t)g->wire_items * (4 * 64 + 16)); }
+static uint8_t* wire_pts(int k) { return sl->wire + (size_t)k * sl->wire_items * 64; }
+static uint8_t* wire_bad() { return sl->wire + (size_t)4 * sl->wire_items * 64; }
+static uint32_t* wire_scratch() { return reinterpret_cast<uint32_t*>(sl->wire + (size_t)sl->wire_items * (4 * 64 + 16)); }
 
 static int launch_decode(decode_params D, hipStream_t s) {
     D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
@@ -888,6 +1044,7 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -896,7 +1053,7 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
     D.src[1] = fe_src{(const uint8_t*)pk, 32, 0};   D.out[1] = wire_pts(1);      // PK
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
@@ -908,6 +1065,7 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -918,7 +1076,7 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     D.src[2] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[2] = wire_pts(2);      // PK
     D.src[3] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[3] = wire_pts(3);      // PK'
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_double((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3),
                                     (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o);
     P.u = fe_src{(const uint8_t*)sig, 96, 0};
@@ -931,6 +1089,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -940,7 +1099,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     D.src[1] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[1] = wire_pts(1);      // PK
     D.src[2] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[2] = wire_pts(2);      // generator
     if (int rc = launch_decode(D, s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
@@ -1002,6 +1161,7 @@ static int ext_single_locked(const void* u, const void* R, const void* PK, const
     if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
@@ -1010,7 +1170,7 @@ static int ext_single_locked(const void* u, const void* R, const void* PK, const
     N.src[1] = ext_src(PK); N.out[1] = wire_pts(1);
     if (int rc = launch_normalize(N, s)) return rc;
     if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_single((const uint8_t*)u, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
@@ -1020,6 +1180,7 @@ static int ext_double_locked(const void* u, const void* R, const void* Rp, const
     if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
@@ -1030,7 +1191,7 @@ static int ext_double_locked(const void* u, const void* R, const void* Rp, const
     N.src[3] = ext_src(PKp); N.out[3] = wire_pts(3);
     if (int rc = launch_normalize(N, s)) return rc;
     if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_double((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3), (const uint8_t*)m, n,
                                     g->tag, g->comb_g, g->comb_gn, o);
     P.pre_malformed = wire_bad();
@@ -1041,6 +1202,7 @@ static int ext_vargen_locked(const void* u, const void* R, const void* PK, const
     if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
+    pick_slot(n);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
@@ -1050,7 +1212,7 @@ static int ext_vargen_locked(const void* u, const void* R, const void* PK, const
     N.src[2] = ext_src(Gen); N.out[2] = wire_pts(2);
     if (int rc = launch_normalize(N, s)) return rc;
     if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, g->workspace};
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_vargen((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
     P.pre_malformed = wire_bad();
     return verify_dev_common(P, status, tally, s);
@@ -1109,6 +1271,7 @@ int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out,
     decode_params D{};
     D.n_src = 1; D.n = n; D.ok = (uint8_t*)ok_out;
     D.src[0] = fe_src{(const uint8_t*)in, 32, 0}; D.out[0] = (uint8_t*)affine_out;
+    big_slot();
     return launch_decode(D, (hipStream_t)stream);
 }
 int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
@@ -1157,7 +1320,8 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     P.c_words = w; w += 8 * g->msig_transcripts;
     uint32_t* d_off = w;
     P.offsets = d_off;
-    P.tags = g->tags_long; P.comb_g = g->comb_g; P.lane_ws = g->workspace;
+    P.tags = g->tags_long; P.comb_g = g->comb_g; P.lane_ws = g->slots[0].workspace;
+    big_slot();
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     for (int pass = 0; pass < 6; ++pass) {
@@ -1218,7 +1382,8 @@ int jjs_challenge_vargen_dev(const void* R, const void* PK, const void* Gen, con
 static int launch_sign(sign_params P, void* stream) {
     if (P.n == 0) return JJS_OK;
     hipStream_t s = (hipStream_t)stream;
-    P.comb_g = g->comb_g; P.comb_gn = g->comb_gn; P.workspace = g->workspace;
+    P.comb_g = g->comb_g; P.comb_gn = g->comb_gn; P.workspace = g->slots[0].workspace;
+    big_slot();
     if (int rc = begin_shared(s)) return rc;
     hipLaunchKernelGGL(sign_kernel, dim3(grid_for(g->grid_sign, P.n)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
@@ -1320,6 +1485,11 @@ int jjs_debug_half_scalars_dev(const void* c, size_t n, void* a_out, void* b_out
 int jjs_debug_skip_phases(unsigned mask) {
     std::lock_guard<std::mutex> lock(L.mu);
     g_skip_phases = mask & 15u;
+    return JJS_OK;
+}
+int jjs_debug_force_path(int which) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    g_force_path = which;
     return JJS_OK;
 }
 int jjs_debug_allow_virtual_devices(int allow) {

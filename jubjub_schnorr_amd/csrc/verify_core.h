@@ -66,6 +66,8 @@ struct verify_params {
     uint32_t own_test_mask;          // bit k: points[k] gets its own subgroup test in the first pass
     uint32_t resolve_lanes;          // lanes per queued item in the resolve pass: 1, 2 or 4 >= points left to test
     uint32_t decoded_points;         // non-zero: every point was produced by decompress_point (on the curve)
+    uint32_t small_mode;             // non-zero: latency path (small_batch.h): prepare_item leaves every point check to the
+                                     // per-point lanes of that path and runs no subgroup test itself
     uint8_t* prep;                   // 65 n bytes: what prepare_kernel hands to verify_kernel (see prep_record)
     uint64_t* pending;               // queue of items left to the resolve pass: item << 1 | equations held
     unsigned long long* pending_count;
@@ -571,8 +573,9 @@ JJS_HD bool point_on_curve_not_identity(const fe_n& u, const fe_n& v) {
     return affine_on_curve(u, v) && !affine_is_identity(u, v);
 }
 
-JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
-    for (int i = 0; i < COMB_WINDOWS; ++i) {
+// digit positions [lo, hi) of the comb; T of the result is valid only when t_last is set
+JJS_HD ext_pt add_comb_range(ext_pt acc, const uint32_t* comb, const words8& k, int lo, int hi, bool t_last) {
+    for (int i = lo; i < hi; ++i) {
         constexpr int per_word = 32 / COMB_BITS;
         const uint32_t digit = (word_at(k, i / per_word) >> ((i % per_word) * COMB_BITS)) & (uint32_t)(COMB_ENTRIES - 1);
         const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
@@ -582,9 +585,12 @@ JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
         fe_t ypx, ymx, t2d;
 #pragma unroll
         for (int j = 0; j < 9; ++j) { ypx.l[j] = w[j]; ymx.l[j] = w[9 + j]; t2d.l[j] = w[18 + j]; }
-        acc = ext_add_affine_niels(acc, ypx, ymx, t2d, i != COMB_WINDOWS - 1);
+        acc = ext_add_affine_niels(acc, ypx, ymx, t2d, t_last || i != hi - 1);
     }
     return acc;
+}
+JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
+    return add_comb_range(acc, comb, k, 0, COMB_WINDOWS, false);
 }
 JJS_HD words8 widen128(const u128w& x) {
     words8 r;
@@ -612,6 +618,24 @@ JJS_HD words8 select_words(bool c, const words8& a, const words8& b) {
     return r;
 }
 
+// (b*u) mod r for the signed half-size scalar b: the fixed-base scalar of the half-size equation
+JJS_HD words8 half_scalar_times_u(const half_scalars& h, const words8& u) {
+    words8 r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
+    words8 w = fr_mont_mul(fr_mont_mul(widen128(h.b), r2), u);          // |b|*u mod r
+    uint32_t nz = 0, borrow = 0;
+    words8 n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        nz |= w.w[i];
+        uint64_t d = (uint64_t)JJS_FR_WORDS[i] - w.w[i] - borrow;
+        n.w[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+    }
+    return select_words(h.b_neg && nz != 0, n, w);                    // b*u mod r
+}
+
 // u*Gen + c*PK == R.
 //  * Fixed generator (comb table present), through half-size scalars:
 //      (b*u mod r)*G + a*PK - b*R == O   with a = b*c (mod r), a, |b| < 2^126,
@@ -634,20 +658,7 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
     int top;
     bool flip1;
     if (fixed) {
-        words8 r2;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r2.w[i] = JJS_FR_R2_WORDS[i];
-        w = fr_mont_mul(fr_mont_mul(widen128(h.b), r2), u);          // |b|*u mod r
-        uint32_t nz = 0, borrow = 0;
-        words8 n;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            nz |= w.w[i];
-            uint64_t d = (uint64_t)JJS_FR_WORDS[i] - w.w[i] - borrow;
-            n.w[i] = (uint32_t)d;
-            borrow = (uint32_t)(d >> 63);
-        }
-        w = select_words(h.b_neg && nz != 0, n, w);                   // b*u mod r
+        w = half_scalar_times_u(h, u);
         s0 = recode_signed4_128(h.a);
         s1 = recode_signed4_128(h.b);
         top = 31;
@@ -727,7 +738,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     r.malformed = malformed;
 
     // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
-    const bool check_points = !JJS_SKIP(P, 1u);
+    const bool check_points = !JJS_SKIP(P, 1u) && !P.small_mode;
     bool valid = true;
     for (uint32_t k = 0; k < (check_points ? P.n_points : 0u); ++k) {
         fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Latency and rate of one device-resident verify call as a function of the batch size: where the GPU path
-starts to pay (a lane verifies one signature start to finish, so a small batch costs one signature's latency).
-One JSON line per size.  Usage: python jubjub_schnorr_amd/tools/batch_size_curve.py [scheme]"""
+"""Latency and rate of one device-resident verify call as a function of the batch size, for both paths of the
+engine: the throughput path (a lane verifies one signature start to finish, so a call costs at least one
+signature's latency) and the latency path (csrc/small_batch.h: a signature spread over 11 / 21 lanes).  Loads the
+profiling build, whose jjs_debug_force_path selects the path regardless of size; "auto" is what the product does.
+One JSON line per (size, path).  Usage: python jubjub_schnorr_amd/tools/batch_size_curve.py [scheme]"""
 import json
 import os
 import sys
@@ -12,24 +14,34 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 import jubjub_schnorr_amd as jjs  # noqa: E402
+from jubjub_schnorr_amd import _ffi  # noqa: E402
 
 
 def main():
     scheme = sys.argv[1] if len(sys.argv) > 1 else "single"
+    _ffi.select_library(_ffi.PROFILING_LIB_PATH)
     eng = jjs.engine()
+    lib = _ffi.lib()
     arrays, expect = bench.make_inputs(eng, scheme, 1 << 20, 0)
-    for n in (1, 64, 256, 1024, 4096, 16384, 65536, 131072, 262144, 1 << 20):
+    sizes = (1, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 1 << 20)
+    for n in sizes:
         call = [arrays[k][:n].contiguous() for k in bench.ARG_ORDER[scheme]]
-        st, _ = eng.verify(scheme, *call)
-        torch.cuda.synchronize()
-        assert torch.equal(st, expect[:n])
-        times = []
-        for _ in range(7):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); eng.verify(scheme, *call); e1.record(); torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1))
-        ms = sorted(times)[len(times) // 2]
-        print(json.dumps({"scheme": scheme, "items": n, "ms": ms, "verifications_per_s": n / (ms * 1e-3)}), flush=True)
+        for path, code in (("auto", 0), ("throughput", 1), ("latency", 2)):
+            if path == "latency" and (n > 16384 or scheme == "vargen"):
+                continue
+            _ffi.check(lib.jjs_debug_force_path(code), "force_path")
+            st, _ = eng.verify(scheme, *call)
+            torch.cuda.synchronize()
+            assert torch.equal(st, expect[:n]), (n, path)
+            times = []
+            for _ in range(9):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); eng.verify(scheme, *call); e1.record(); torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+            ms = sorted(times)[len(times) // 2]
+            print(json.dumps({"scheme": scheme, "items": n, "path": path, "ms": ms, "ms_min": min(times),
+                              "verifications_per_s": n / (ms * 1e-3)}), flush=True)
+    lib.jjs_debug_force_path(0)
 
 
 if __name__ == "__main__":

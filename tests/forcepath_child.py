@@ -1,0 +1,43 @@
+"""Child process of test_gpu_parity.py::test_both_paths_at_every_size: loads the profiling build and runs the
+same ragged batches through the throughput path and through the latency path (jjs_debug_force_path), every status
+against the oracle.  The product library chooses between the two by size only; this pins each of them at sizes
+the other normally serves."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.join(HERE, "..", "oracle"), os.path.join(HERE, "..")]
+
+from helpers import ARG_ORDER, edge_cases, make_batch, oracle_verify, torsion_grid  # noqa: E402
+
+
+def main() -> None:
+    import torch
+    import jubjub_schnorr_amd as jjs
+    from jubjub_schnorr_amd import _ffi
+    _ffi.select_library(_ffi.PROFILING_LIB_PATH)
+    eng = jjs.engine()
+    lib = _ffi.lib()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for scheme in ("single", "double"):
+        cases = [make_batch(scheme, n, seed=700 + n, n_keys=16) for n in (1, 3, 63, 65, 257, 1000, 5000)]
+        cases += [edge_cases(scheme), torsion_grid(scheme, reps=2, extra=0 if scheme == "single" else 100)]
+        for b in cases:
+            want = oracle_verify(scheme, b)
+            for path in (1, 2):
+                assert lib.jjs_debug_force_path(path) == 0
+                st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
+                assert st.cpu().numpy().tolist() == want.tolist(), (scheme, len(want), path)
+                assert tally.cpu().numpy().tolist() == [int((want == k).sum()) for k in range(4)], (scheme, len(want), path)
+                _, t2 = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]], want_status=False)
+                assert t2.cpu().numpy().tolist() == tally.cpu().numpy().tolist()
+                st_h, tally_h = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])           # host buffers
+                assert st_h.tolist() == want.tolist() and tally_h.tolist() == tally.cpu().numpy().tolist()
+    lib.jjs_debug_force_path(0)
+    print("FORCEPATH OK")
+
+
+if __name__ == "__main__":
+    main()

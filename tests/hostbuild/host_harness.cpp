@@ -7,6 +7,7 @@
 #include "schemes.h"
 #include "decode.h"
 #include "normalize.h"
+#include "small_batch.h"
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
 
@@ -70,7 +71,42 @@ static void run(verify_params P) {
     }
 }
 
+// the latency path of csrc/small_batch.h, every role of an item run in turn on this thread
+static void run_small(verify_params P) {
+    std::vector<uint8_t> prep(65 * P.n + 64), ok(4 * P.n + 4);
+    std::vector<uint32_t> tables(sb_table_words_per_item(P.n_eq) * P.n + 4);
+    small_params S{};
+    P.small_mode = 1;
+    P.prep = (uint8_t*)(((uintptr_t)prep.data() + 15) & ~(uintptr_t)15);
+    S.V = P;
+    S.tables = (uint32_t*)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
+    S.point_ok = ok.data();
+    for (uint64_t i = 0; i < P.n; ++i) {
+        const uint32_t st = sb_verify_item_serial(S, i);
+        if (P.status) P.status[i] = (uint8_t)st;
+        if (P.tally) P.tally[st]++;
+    }
+}
+
 extern "C" {
+
+int jjs_host_verify_small_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                                 uint8_t* status, uint64_t* tally) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_small(params_single(u, R, PK, m, n, g_comb_g.data(), out_ptrs{status, t, nullptr, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+int jjs_host_verify_small_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                                 const uint8_t* m, size_t n, uint8_t* status, uint64_t* tally) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_small(params_double(u, R, Rp, PK, PKp, m, n, (const uint8_t*)g_tag, g_comb_g.data(), g_comb_gn.data(),
+                            out_ptrs{status, t, nullptr, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
 
 int jjs_host_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
     for (size_t i = 0; i < n; ++i) {

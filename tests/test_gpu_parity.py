@@ -495,6 +495,50 @@ def test_differential_32k_against_c_oracle(eng, scheme):
     assert set(want.tolist()) == {0, 1, 2, 3}
 
 
+def test_both_paths_at_every_size():
+    """Throughput path and latency path forced in turn (profiling build, child process) on ragged sizes, edge
+    cases and the torsion grid."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "forcepath_child.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "FORCEPATH OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 8192)])
+def test_path_boundary(eng, scheme, limit):
+    """The largest batch the latency path takes and the smallest one the throughput path takes, both against the
+    oracle (the product chooses by size: csrc/jjs_gpu.hip SMALL_PATH_MAX_ITEMS)."""
+    b = make_batch(scheme, limit + 1, seed=4711, n_keys=64)
+    want = oracle_verify(scheme, b)
+    for n in (limit, limit + 1):
+        st, tally = eng.verify(scheme, *[dev(b[k][:n]) for k in ARG_ORDER[scheme]])
+        assert (host(st) == want[:n]).all()
+        assert host(tally).tolist() == [int((want[:n] == k).sum()) for k in range(4)]
+
+
+def test_small_calls_on_different_streams_overlap_safely(eng):
+    """Small calls take the engine's small slots in turn (disjoint buffers, no ordering between slots); with more
+    streams than slots two calls share one and are ordered by its event.  Results must not depend on any of it."""
+    import torch
+    specs = [("single", 3000), ("double", 2000), ("vargen", 1500), ("single", 4096), ("double", 700), ("single", 1)]
+    batches = [make_batch(s, n, seed=1200 + i, n_keys=16) for i, (s, n) in enumerate(specs)]
+    args = [[dev(b[k]) for k in ARG_ORDER[s]] for b, (s, _) in zip(batches, specs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in specs]
+    outs = []
+    for _ in range(4):
+        outs = []
+        for a, (s, _), stream in zip(args, specs, streams):
+            with torch.cuda.stream(stream):
+                outs.append(eng.verify(s, *a))
+    torch.cuda.synchronize()
+    for (st, tally), b, (s, _) in zip(outs, batches, specs):
+        want = oracle_verify(s, b)
+        assert host(st).tolist() == want.tolist()
+        assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+
+
 def test_calls_on_different_streams_do_not_interfere(eng):
     """The engine's workspaces are shared; launches from different streams must be ordered by the library."""
     import torch

@@ -333,3 +333,19 @@ def test_normalize_extended_points():
                     continue
                 want = bytes(64) if (j, i) in zero_rows else aff[j][i].tobytes()
                 assert outs[j][i].tobytes() == want, (k, n, lanes, j, i)
+
+
+# ---- latency path for small batches (csrc/small_batch.h) -----------------------------------------------------
+@pytest.mark.parametrize("scheme", ["single", "double"])
+def test_small_batch_path_matches_oracle(scheme):
+    """The same statuses from the path that cuts a signature into chain / point / hash / piece lanes: mixed batch,
+    hand-built edge cases and every pair of small-order components."""
+    b = make_batch(scheme, 48, seed=61, n_keys=8)
+    want = oracle_verify(scheme, b)
+    st, tally = hl.verify_small(scheme, b)
+    assert st.tolist() == want.tolist()
+    assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    b = edge_cases(scheme)
+    assert hl.verify_small(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
+    b = torsion_grid(scheme, reps=1, extra=0 if scheme == "single" else 40)
+    assert hl.verify_small(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
