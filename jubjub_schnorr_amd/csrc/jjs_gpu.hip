@@ -116,14 +116,14 @@ __global__ __launch_bounds__(BLOCK, 2) void small_a_kernel(small_params S, uint3
         return;
     }
     const uint32_t cb = b - hash_blocks;
-    if (cb < SB_POSITIONS * chain_blocks_per_pos) {
-        const uint32_t k = SB_POSITIONS - 1 - cb / chain_blocks_per_pos;           // block-uniform position
+    if (cb < S.positions * chain_blocks_per_pos) {
+        const uint32_t k = S.positions - 1 - cb / chain_blocks_per_pos;            // block-uniform position
         const uint64_t r = (uint64_t)(cb % chain_blocks_per_pos) * BLOCK + threadIdx.x;
         const uint32_t per_item = 2 * S.V.n_eq;                                     // (equation, PK | R)
         if (r < n * per_item) sb_chain_lane(S, r / per_item, (uint32_t)(r % per_item) >> 1, (uint32_t)r & 1u, k);
         return;
     }
-    const uint64_t r = (uint64_t)(cb - SB_POSITIONS * chain_blocks_per_pos) * BLOCK + threadIdx.x;
+    const uint64_t r = (uint64_t)(cb - S.positions * chain_blocks_per_pos) * BLOCK + threadIdx.x;
     if (r < n * S.V.n_points) sb_point_lane(S, r / S.V.n_points, (uint32_t)(r % S.V.n_points));
 }
 
@@ -140,23 +140,35 @@ __device__ __forceinline__ ext_pt dpp_quad(const ext_pt& p) {
     }
     return r;
 }
-// Phase B: four adjacent lanes per equation (eight per item for the double scheme); every lane of a group ends
-// with the whole left side of its equation, lane 0 of the item writes the verdict.
+__device__ __forceinline__ ext_pt shfl_xor_ext(const ext_pt& p, int mask) {
+    ext_pt r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = (uint32_t)__shfl_xor((int)p.x.l[i], mask);
+        r.y.l[i] = (uint32_t)__shfl_xor((int)p.y.l[i], mask);
+        r.z.l[i] = (uint32_t)__shfl_xor((int)p.z.l[i], mask);
+        r.t.l[i] = (uint32_t)__shfl_xor((int)p.t.l[i], mask);
+    }
+    return r;
+}
+// Phase B: `positions` adjacent lanes per equation (twice that per item for the double scheme); every lane of a
+// group ends with the whole left side of its equation, lane 0 of the item writes the verdict.
 __global__ __launch_bounds__(BLOCK, 2) void small_b_kernel(small_params S) {
     const uint64_t n = S.V.n;
-    const uint32_t lanes_per_item = SB_POSITIONS * S.V.n_eq;
+    const uint32_t pos = S.positions, lanes_per_item = pos * S.V.n_eq;
     const uint64_t total = n * lanes_per_item;
     const uint64_t idx = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = idx < total;              // groups are whole: total is a multiple of the group size
     const uint64_t ii = active ? idx : total - 1;
     const uint64_t item = ii / lanes_per_item;
-    const uint32_t sub = (uint32_t)(ii % lanes_per_item), e = sub >> 2, k = sub & 3u;
+    const uint32_t sub = (uint32_t)(ii % lanes_per_item), e = sub / pos, k = sub % pos;
     const prep_record r = load_prep(S.V.prep, n, item);
     ext_pt acc = sb_piece(S, item, e, k, r);
     acc = sb_add(acc, dpp_quad<0xB1>(acc));       // quad_perm [1,0,3,2]: partner lane ^ 1
     acc = sb_add(acc, dpp_quad<0x4E>(acc));       // quad_perm [2,3,0,1]: partner lane ^ 2
+    if (pos == 8) acc = sb_add(acc, shfl_xor_ext(acc, 4));
     bool eq_ok = ext_is_identity(acc);
-    if (S.V.n_eq == 2) eq_ok = (__shfl_xor((int)eq_ok, 4) != 0) && eq_ok;
+    if (S.V.n_eq == 2) eq_ok = (__shfl_xor((int)eq_ok, (int)pos) != 0) && eq_ok;
     const uint32_t st = sb_status(r.malformed, sb_points_ok(S, item), eq_ok);
     const bool writer = active && sub == 0;
     if (writer && S.V.status) S.V.status[item] = (uint8_t)st;
@@ -331,7 +343,9 @@ constexpr int N_SMALL_SLOTS = 3;
 constexpr size_t SMALL_SLOT_ITEMS = 16384;
 // largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
 // path is faster (tools/batch_size_curve.py)
-constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 8192};
+constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
+// up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
+constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 
 struct device_state {
     int device = -1;               // HIP device ordinal
@@ -419,6 +433,7 @@ int grid_for(int resident, size_t n) {
 uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_prof.so only)
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
+int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
 #endif
 
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
@@ -478,19 +493,24 @@ int ensure_small(size_t bytes) {
 
 // Latency path (small_batch.h): two launches, every signature spread over 11 (single) or 21 (double) lanes.
 int launch_small(verify_params P, hipStream_t s) {
-    const size_t table_bytes = P.n * sb_table_words_per_item(P.n_eq) * sizeof(uint32_t);
+    uint32_t positions = P.n <= SMALL_PATH_FINE_ITEMS[P.n_eq] ? 8 : 4;
+#if defined(JJS_PROFILING)
+    if (g_force_positions) positions = (uint32_t)g_force_positions;
+#endif
+    const size_t table_bytes = P.n * sb_table_words_per_item(P.n_eq, positions) * sizeof(uint32_t);
     if (int rc = ensure_small(table_bytes + 4 * P.n + 64)) return rc;
     small_params S{};
     P.small_mode = 1;
     S.V = P;
     S.tables = reinterpret_cast<uint32_t*>(sl->small);
     S.point_ok = sl->small + table_bytes;
+    S.positions = positions;
     const unsigned hash_blocks = (unsigned)((P.n + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + SB_POSITIONS * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,
+    hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + positions * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,
                        (uint32_t)hash_blocks, (uint32_t)chain_blocks);
-    hipLaunchKernelGGL(small_b_kernel, dim3((unsigned)((P.n * P.n_eq * SB_POSITIONS + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S);
+    hipLaunchKernelGGL(small_b_kernel, dim3((unsigned)((P.n * P.n_eq * positions + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S);
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }
@@ -1489,7 +1509,8 @@ int jjs_debug_skip_phases(unsigned mask) {
 }
 int jjs_debug_force_path(int which) {
     std::lock_guard<std::mutex> lock(L.mu);
-    g_force_path = which;
+    g_force_path = which & 3;                       // 0 by size, 1 throughput, 2 latency
+    g_force_positions = (which >> 4) == 4 || (which >> 4) == 8 ? (which >> 4) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
     return JJS_OK;
 }
 int jjs_debug_allow_virtual_devices(int allow) {

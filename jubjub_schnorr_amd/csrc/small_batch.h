@@ -11,7 +11,7 @@
 //     hash     1 lane / item          encodings, Poseidon challenge, truncated Euclid (a, b)        [prepare_item]
 //     chain    8 lanes / equation     P_k = 2^(32k) * P for P in {PK, R}, k = 0..3, and the window table
 //                                     {0..8} * P_k of each (the loop of phase B then needs no doubling chain
-//                                     longer than 28)
+//                                     longer than 28); 16 lanes and 16-bit pieces for the smallest batches
 //     point    1 lane / point         is_on_curve, !is_identity, is_torsion_free (pairing test) for every point:
 //                                     no combined test, no resolve pass
 //   phase B, 4 adjacent lanes / equation:
@@ -30,22 +30,23 @@
 
 namespace jjs {
 
-constexpr int SB_POSITIONS = 4;                    // pieces of 32 bits of the 128-bit half-size scalars
-constexpr int SB_PIECE_WINDOWS = 8;                // signed 4-bit windows per piece
-constexpr int SB_PIECE_DOUBLINGS = 32;             // P_{k+1} = 2^32 * P_k
-constexpr int SB_COMB_PER_LANE = COMB_WINDOWS / SB_POSITIONS;
-static_assert(COMB_WINDOWS % SB_POSITIONS == 0, "the comb digits are shared out evenly");
+// The 128-bit half-size scalars are cut into `positions` pieces (4 or 8, chosen per launch: the finer cut halves
+// the tail of the critical path again and doubles the work of the chain lanes, so it is used for the smallest
+// batches only).  Piece k covers bits [128 k / positions, 128 (k + 1) / positions).
+constexpr int SB_MAX_POSITIONS = 8;
+static_assert(COMB_WINDOWS % SB_MAX_POSITIONS == 0, "the comb digits are shared out evenly");
 
 struct small_params {
     verify_params V;        // scheme descriptor with small_mode = 1; V.prep holds the prep records
     uint32_t* tables;       // [item][equation][0 = PK, 1 = R][position][TABLE_WORDS]
     uint8_t* point_ok;      // [item][4]: V.points[p] is on the curve, not the identity, torsion-free
+    uint32_t positions;     // 4 or 8
 };
 
 JJS_HD uint32_t* sb_table(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
-    return S.tables + ((((item * S.V.n_eq + e) * 2 + pt) * SB_POSITIONS) + k) * (size_t)TABLE_WORDS;
+    return S.tables + ((((item * S.V.n_eq + e) * 2 + pt) * S.positions) + k) * (size_t)TABLE_WORDS;
 }
-JJS_HD size_t sb_table_words_per_item(uint32_t n_eq) { return (size_t)n_eq * 2 * SB_POSITIONS * TABLE_WORDS; }
+JJS_HD size_t sb_table_words_per_item(uint32_t n_eq, uint32_t positions) { return (size_t)n_eq * 2 * positions * TABLE_WORDS; }
 
 // table[j] = j * P for j = 0..8, P projective
 JJS_HD void build_point_table_ext(uint32_t* tab, const ext_pt& p1) {
@@ -64,7 +65,7 @@ JJS_HD void build_point_table_ext(uint32_t* tab, const ext_pt& p1) {
 JJS_HD void sb_hash_item(const small_params& S, uint64_t item) {
     store_prep(S.V.prep, S.V.n, item, prepare_item(S.V, item));
 }
-// window table of 2^(32k) * P, P = PK (pt 0) or R (pt 1) of equation e
+// window table of 2^(128 k / positions) * P, P = PK (pt 0) or R (pt 1) of equation e
 JJS_HD void sb_chain_lane(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
     const fe_src& src = pt == 0 ? S.V.eq[e].pk : S.V.eq[e].r;
     const fe_n pu = load_fq(src, item), pv = load_fq(src, item, 32);
@@ -74,7 +75,7 @@ JJS_HD void sb_chain_lane(const small_params& S, uint64_t item, uint32_t e, uint
         return;
     }
     ext_pt p = ext_from_affine(pu, pv);
-    const int n_dbl = SB_PIECE_DOUBLINGS * (int)k;
+    const int n_dbl = (128 / (int)S.positions) * (int)k;
     for (int i = 0; i < n_dbl; ++i) p = ext_double(p, i == n_dbl - 1);
     build_point_table_ext(tab, p);
 }
@@ -88,7 +89,8 @@ JJS_HD void sb_point_lane(const small_params& S, uint64_t item, uint32_t p) {
 }
 
 // ---- phase B ------------------------------------------------------------------------------------------
-// lane k of equation e: windows 8k..8k+7 of (a over PK_k, -b over R_k) and comb digits 4k..4k+3 of (b*u)*G
+// lane k of equation e: its 32 / positions signed windows of (a over PK_k, -b over R_k) and its 16 / positions comb
+// digits of (b*u)*G
 JJS_HD ext_pt sb_piece(const small_params& S, uint64_t item, uint32_t e, uint32_t k, const prep_record& r) {
     const words8 u = load_words(S.V.u, item);
     const words8 w = half_scalar_times_u(r.h, u);
@@ -96,17 +98,18 @@ JJS_HD ext_pt sb_piece(const small_params& S, uint64_t item, uint32_t e, uint32_
     const uint32_t* t0 = sb_table(S, item, e, 0, k);
     const uint32_t* t1 = sb_table(S, item, e, 1, k);
     const bool flip1 = !r.h.b_neg;                                   // table 1 contributes -b*R
+    const int windows = 32 / (int)S.positions, comb_digits = COMB_WINDOWS / (int)S.positions;
     ext_pt acc = ext_identity();
-    for (int win = SB_PIECE_WINDOWS - 1; win >= 0; --win) {
-        if (win != SB_PIECE_WINDOWS - 1) {
+    for (int win = windows - 1; win >= 0; --win) {
+        if (win != windows - 1) {
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) acc = ext_double(acc, j == 3);
         }
-        const int nib = SB_PIECE_WINDOWS * (int)k + win;             // digit 31 is the unsigned top digit
+        const int nib = windows * (int)k + win;                      // digit 31 is the unsigned top digit
         acc = add_window(acc, t0, s0, nib, true, 31, false);
         acc = add_window(acc, t1, s1, nib, win == 0, 31, flip1);     // doublings follow, except before the comb digits
     }
-    return add_comb_range(acc, S.V.eq[e].comb, w, SB_COMB_PER_LANE * (int)k, SB_COMB_PER_LANE * (int)k + SB_COMB_PER_LANE, true);
+    return add_comb_range(acc, S.V.eq[e].comb, w, comb_digits * (int)k, comb_digits * (int)k + comb_digits, true);
 }
 JJS_HD ext_pt sb_add(const ext_pt& a, const ext_pt& b) { return ext_add_niels(a, to_niels(b), false, true); }
 
@@ -125,14 +128,16 @@ JJS_HD uint32_t sb_verify_item_serial(const small_params& S, uint64_t item) {
     sb_hash_item(S, item);
     for (uint32_t e = 0; e < S.V.n_eq; ++e)
         for (uint32_t pt = 0; pt < 2; ++pt)
-            for (uint32_t k = 0; k < SB_POSITIONS; ++k) sb_chain_lane(S, item, e, pt, k);
+            for (uint32_t k = 0; k < S.positions; ++k) sb_chain_lane(S, item, e, pt, k);
     for (uint32_t p = 0; p < S.V.n_points; ++p) sb_point_lane(S, item, p);
     const prep_record r = load_prep(S.V.prep, S.V.n, item);
     bool eq_ok = true;
     for (uint32_t e = 0; e < S.V.n_eq; ++e) {
-        ext_pt part[SB_POSITIONS];
-        for (uint32_t k = 0; k < SB_POSITIONS; ++k) part[k] = sb_piece(S, item, e, k, r);
-        const ext_pt total = sb_add(sb_add(part[0], part[1]), sb_add(part[2], part[3]));
+        ext_pt part[SB_MAX_POSITIONS];
+        for (uint32_t k = 0; k < S.positions; ++k) part[k] = sb_piece(S, item, e, k, r);
+        for (uint32_t step = 1; step < S.positions; step <<= 1)          // the device's shuffle tree: lane ^ 1, ^ 2, ^ 4
+            for (uint32_t k = 0; k < S.positions; k += 2 * step) part[k] = sb_add(part[k], part[k + step]);
+        const ext_pt total = part[0];
         eq_ok = ext_is_identity(total) && eq_ok;
     }
     return sb_status(r.malformed, sb_points_ok(S, item), eq_ok);

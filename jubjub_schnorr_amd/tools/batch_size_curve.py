@@ -26,8 +26,8 @@ def main():
     sizes = (1, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 1 << 20)
     for n in sizes:
         call = [arrays[k][:n].contiguous() for k in bench.ARG_ORDER[scheme]]
-        for path, code in (("auto", 0), ("throughput", 1), ("latency", 2)):
-            if path == "latency" and (n > 16384 or scheme == "vargen"):
+        for path, code in (("auto", 0), ("throughput", 1), ("latency-4", 0x42), ("latency-8", 0x82)):
+            if path.startswith("latency") and (n > 16384 or scheme == "vargen"):
                 continue
             _ffi.check(lib.jjs_debug_force_path(code), "force_path")
             st, _ = eng.verify(scheme, *call)

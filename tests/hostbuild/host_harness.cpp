@@ -72,10 +72,11 @@ static void run(verify_params P) {
 }
 
 // the latency path of csrc/small_batch.h, every role of an item run in turn on this thread
-static void run_small(verify_params P) {
+static void run_small(verify_params P, uint32_t positions) {
     std::vector<uint8_t> prep(65 * P.n + 64), ok(4 * P.n + 4);
-    std::vector<uint32_t> tables(sb_table_words_per_item(P.n_eq) * P.n + 4);
+    std::vector<uint32_t> tables(sb_table_words_per_item(P.n_eq, positions) * P.n + 4);
     small_params S{};
+    S.positions = positions;
     P.small_mode = 1;
     P.prep = (uint8_t*)(((uintptr_t)prep.data() + 15) & ~(uintptr_t)15);
     S.V = P;
@@ -91,19 +92,19 @@ static void run_small(verify_params P) {
 extern "C" {
 
 int jjs_host_verify_small_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
-                                 uint8_t* status, uint64_t* tally) {
+                                 uint8_t* status, uint64_t* tally, int positions) {
     ensure_tables();
     unsigned long long t[4] = {0, 0, 0, 0};
-    run_small(params_single(u, R, PK, m, n, g_comb_g.data(), out_ptrs{status, t, nullptr, nullptr}));
+    run_small(params_single(u, R, PK, m, n, g_comb_g.data(), out_ptrs{status, t, nullptr, nullptr}), (uint32_t)positions);
     if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
     return 0;
 }
 int jjs_host_verify_small_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
-                                 const uint8_t* m, size_t n, uint8_t* status, uint64_t* tally) {
+                                 const uint8_t* m, size_t n, uint8_t* status, uint64_t* tally, int positions) {
     ensure_tables();
     unsigned long long t[4] = {0, 0, 0, 0};
     run_small(params_double(u, R, Rp, PK, PKp, m, n, (const uint8_t*)g_tag, g_comb_g.data(), g_comb_gn.data(),
-                            out_ptrs{status, t, nullptr, nullptr}));
+                            out_ptrs{status, t, nullptr, nullptr}), (uint32_t)positions);
     if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
     return 0;
 }

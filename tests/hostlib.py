@@ -146,12 +146,12 @@ def normalize(ext_arrays, lanes=1):
     return outs, bad
 
 
-def verify_small(scheme, b):
-    """The latency path (csrc/small_batch.h) on the CPU build: single and double schemes."""
+def verify_small(scheme, b, positions=4):
+    """The latency path (csrc/small_batch.h) on the CPU build: single and double schemes, 4 or 8 pieces."""
     from helpers import ARG_ORDER
     args = [_c(b[k]) for k in ARG_ORDER[scheme]]
     n = len(args[0])
     st = np.empty(n, np.uint8); tally = np.zeros(4, np.uint64)
     fn = getattr(load(), "jjs_host_verify_small_" + scheme)
-    fn(*[_p(a) for a in args], ctypes.c_size_t(n), _p(st), _p(tally))
+    fn(*[_p(a) for a in args], ctypes.c_size_t(n), _p(st), _p(tally), int(positions))
     return st, tally

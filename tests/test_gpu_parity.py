@@ -505,10 +505,10 @@ def test_both_paths_at_every_size():
     assert p.returncode == 0 and "FORCEPATH OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 8192)])
+@pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 16384), ("single", 4096), ("double", 4096)])
 def test_path_boundary(eng, scheme, limit):
-    """The largest batch the latency path takes and the smallest one the throughput path takes, both against the
-    oracle (the product chooses by size: csrc/jjs_gpu.hip SMALL_PATH_MAX_ITEMS)."""
+    """Either side of the sizes at which the product changes method (csrc/jjs_gpu.hip SMALL_PATH_FINE_ITEMS: 8 -> 4
+    pieces on the latency path; SMALL_PATH_MAX_ITEMS: latency -> throughput path), against the oracle."""
     b = make_batch(scheme, limit + 1, seed=4711, n_keys=64)
     want = oracle_verify(scheme, b)
     for n in (limit, limit + 1):

@@ -336,16 +336,17 @@ def test_normalize_extended_points():
 
 
 # ---- latency path for small batches (csrc/small_batch.h) -----------------------------------------------------
+@pytest.mark.parametrize("positions", [4, 8])
 @pytest.mark.parametrize("scheme", ["single", "double"])
-def test_small_batch_path_matches_oracle(scheme):
+def test_small_batch_path_matches_oracle(scheme, positions):
     """The same statuses from the path that cuts a signature into chain / point / hash / piece lanes: mixed batch,
     hand-built edge cases and every pair of small-order components."""
     b = make_batch(scheme, 48, seed=61, n_keys=8)
     want = oracle_verify(scheme, b)
-    st, tally = hl.verify_small(scheme, b)
+    st, tally = hl.verify_small(scheme, b, positions)
     assert st.tolist() == want.tolist()
     assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
     b = edge_cases(scheme)
-    assert hl.verify_small(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
+    assert hl.verify_small(scheme, b, positions)[0].tolist() == oracle_verify(scheme, b).tolist()
     b = torsion_grid(scheme, reps=1, extra=0 if scheme == "single" else 40)
-    assert hl.verify_small(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
+    assert hl.verify_small(scheme, b, positions)[0].tolist() == oracle_verify(scheme, b).tolist()
