@@ -157,13 +157,16 @@ int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t*
  * PK, R, S (N x 64 affine); m is B x 32.  `offsets` is a HOST array of B + 1 entries starting at 0; every
  * transcript needs 1..256 participants (otherwise -1, the reference's InvalidMultisigTranscript).
  * Outputs (device): share_status[i] = 0 when z_i*G + (c*d_i)*PK_i == R_i + a*S_i, 4 (InvalidMultisigShare)
- * when not, 3 for a non-canonical encoding; agg_pk[t] = aggregate_pk(pk_vec) (64 B affine); and what
- * `combine` returns when every share is valid: sig_u[t] = sum z_i (32 B), sig_R[t] = RSa (64 B affine).
+ * when not, 3 for a non-canonical encoding (z_i, a coordinate, or the transcript's m); transcript_status[t]
+ * (B bytes, nullable) = 0 when `combine` returns a signature, else the status of the transcript's first failing
+ * share (the reference's `combine` stops there, src/multisig.rs:340-353); agg_pk[t] = aggregate_pk(pk_vec) (64 B
+ * affine); and what `combine` returns: sig_u[t] = sum z_i (32 B), sig_R[t] = RSa (64 B affine) -- both all-zero
+ * for a transcript whose status is not 0 (no signature comes out of bad shares).
  * Like the reference, the points are not validated.  Asynchronous on `stream`. */
 #define JJS_STATUS_INVALID_SHARE 4
 int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const void* S, const void* m,
-                             const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* agg_pk,
-                             void* sig_u, void* sig_R, void* stream);
+                             const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* transcript_status,
+                             void* agg_pk, void* sig_u, void* sig_R, void* stream);
 
 /* ---- transcript parity (debug export): c_out = n x 32 bytes, the 250-bit challenge per item ---- */
 int jjs_challenge_single_dev(const void* R, const void* PK, const void* m, size_t n, void* c_out, void* stream);

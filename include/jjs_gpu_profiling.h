@@ -14,7 +14,8 @@ extern "C" {
 #endif
 
 /* Ablations (results become meaningless): skip phases of the verify kernels in later launches; bit0 = point
- * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars); 0 restores the full path. */
+ * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars), bit4 = every window / comb
+ * lookup of every lane reads one shared, cached table entry (what the gathers cost); 0 restores the full path. */
 int jjs_debug_skip_phases(unsigned mask);
 /* Path selection for A/B timing (results stay exact): 0 = by batch size (product behaviour), 1 = always the
  * throughput path, 2 = the latency path for every single / double call of at most 16 384 items; 0x42 / 0x82 = the

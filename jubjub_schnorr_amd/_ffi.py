@@ -42,7 +42,7 @@ SIGNATURES = {
     "jjs_verify_single_ext": [_P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_double_ext": [_P, _P, _P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_vargen_ext": [_P, _P, _P, _P, _P, _Z, _P, _P],
-    "jjs_multisig_combine_dev": [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P],
+    "jjs_multisig_combine_dev": [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P],
     "jjs_decompress_dev": [_P, _Z, _P, _P, _P],
     "jjs_compress_dev": [_P, _Z, _P, _P],
     "jjs_challenge_single_dev": [_P, _P, _P, _Z, _P, _P],

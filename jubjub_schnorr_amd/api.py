@@ -180,20 +180,22 @@ class Engine:
     def multisig_combine(self, z, PK, R, S, m, offsets):
         """Batch `verify_share` + `combine` + `aggregate_pk` over many transcripts (reference src/multisig.rs).
         z (N, 32), PK / R / S (N, 64), m (B, 32): torch CUDA uint8; offsets: B + 1 ints (host).  Returns
-        (share_status (N,), agg_pk (B, 64), sig_u (B, 32), sig_R (B, 64)); share_status 0 ok / 3 / 4."""
+        (share_status (N,), agg_pk (B, 64), sig_u (B, 32), sig_R (B, 64), transcript_status (B,)); statuses 0 ok / 3 / 4;
+        sig_u / sig_R are zero for a transcript whose status is not 0 (`combine` returns an error, not a signature)."""
         import torch
         offs = np.ascontiguousarray(offsets, dtype=np.uint32)
         B, N = len(offs) - 1, z.shape[0]
         dev_ = z.device
         new = lambda rows, w: torch.empty((max(rows, 1), w), dtype=torch.uint8, device=dev_)[:rows]  # noqa: E731
         status = torch.empty(max(N, 1), dtype=torch.uint8, device=dev_)[:N]
+        tstatus = torch.empty(max(B, 1), dtype=torch.uint8, device=dev_)[:B]
         agg, su, sr = new(B, 64), new(B, 32), new(B, 64)
         o = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         _ffi.check(self._lib.jjs_multisig_combine_dev(self._dev_ptr(z, 32, N), self._dev_ptr(PK, 64, N), self._dev_ptr(R, 64, N),
                                                       self._dev_ptr(S, 64, N), self._dev_ptr(m, 32, B),
-                                                      offs.ctypes.data_as(ctypes.c_void_p), B, o(status), o(agg), o(su), o(sr),
-                                                      self._stream()), "jjs_multisig_combine_dev")
-        return status, agg, su, sr
+                                                      offs.ctypes.data_as(ctypes.c_void_p), B, o(status), o(tstatus), o(agg), o(su),
+                                                      o(sr), self._stream()), "jjs_multisig_combine_dev")
+        return status, agg, su, sr, tstatus
 
     def challenge(self, scheme: str, *arrays):
         """250-bit challenge per item (torch CUDA tensors): single (R, PK, m); double (R, R', PK, PK', m);

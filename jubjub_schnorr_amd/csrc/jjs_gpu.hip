@@ -256,12 +256,12 @@ __global__ __launch_bounds__(BLOCK) void derive_kernel(const uint8_t* sk, uint64
     }
 }
 
-// multisig passes: 0 map, 1 delinearisation, 2 aggregate key + a, 3 commitments, 4 RSa + c + u, 5 shares
+// multisig passes: 0 map, 1 delinearisation, 2 aggregate key + a, 3 commitments, 4 RSa + c + u, 5 shares, 6 verdicts
 __global__ __launch_bounds__(BLOCK) void msig_kernel(msig_params P, int pass) {
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     uint32_t* ws = P.lane_ws + gtid * WS_WORDS_PER_LANE;
-    const bool per_transcript = (pass == 0 || pass == 2 || pass == 4);
+    const bool per_transcript = (pass == 0 || pass == 2 || pass == 4 || pass == 6);
     const uint64_t count = per_transcript ? P.n_transcripts : P.n_total;
     for (uint64_t i = gtid; i < count; i += total) {
         switch (pass) {
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(BLOCK) void msig_kernel(msig_params P, int pass) {
         case 2: msig_agg_item(P, (uint32_t)i); break;
         case 3: msig_commit_item(P, i, ws); break;
         case 4: msig_final_item(P, (uint32_t)i); break;
-        default: msig_share_item(P, i, ws); break;
+        case 5: msig_share_item(P, i, ws); break;
+        default: msig_verdict_item(P, (uint32_t)i); break;
         }
     }
 }
@@ -1307,8 +1308,8 @@ int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream) {
 
 // ---- multisig: batch verify_share / combine -------------------------------------------
 int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const void* S, const void* m,
-                             const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* agg_pk,
-                             void* sig_u, void* sig_R, void* stream) {
+                             const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* transcript_status,
+                             void* agg_pk, void* sig_u, void* sig_R, void* stream) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
     if (n_transcripts == 0) return JJS_OK;
@@ -1331,6 +1332,7 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     P.z = (const uint8_t*)z; P.PK = (const uint8_t*)PK; P.R = (const uint8_t*)R; P.S = (const uint8_t*)S; P.m = (const uint8_t*)m;
     P.n_transcripts = (uint32_t)n_transcripts; P.n_total = n;
     P.share_status = (uint8_t*)share_status; P.agg_pk = (uint8_t*)agg_pk; P.sig_u = (uint8_t*)sig_u; P.sig_R = (uint8_t*)sig_R;
+    P.transcript_status = (uint8_t*)transcript_status;
     uint32_t* w = (uint32_t*)g->msig;
     P.tr_of = w; w += g->msig_items;
     P.d_words = w; w += 8 * g->msig_items;
@@ -1344,8 +1346,8 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     big_slot();
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    for (int pass = 0; pass < 6; ++pass) {
-        const size_t count = (pass == 0 || pass == 2 || pass == 4) ? n_transcripts : n;
+    for (int pass = 0; pass < 7; ++pass) {
+        const size_t count = (pass == 0 || pass == 2 || pass == 4 || pass == 6) ? n_transcripts : n;
         hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g->grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
     }
     HIP_TRY(hipGetLastError());
@@ -1504,7 +1506,7 @@ int jjs_debug_half_scalars_dev(const void* c, size_t n, void* a_out, void* b_out
 // include/jjs_gpu_profiling.h: these two exist only in libjjs_gpu_prof.so
 int jjs_debug_skip_phases(unsigned mask) {
     std::lock_guard<std::mutex> lock(L.mu);
-    g_skip_phases = mask & 15u;
+    g_skip_phases = mask & 31u;
     return JJS_OK;
 }
 int jjs_debug_force_path(int which) {

@@ -24,6 +24,7 @@ struct msig_params {
     uint64_t n_total;
     uint8_t* share_status;               // N bytes: 0 ok, 3 malformed encoding, 4 invalid share
     uint8_t *agg_pk, *sig_u, *sig_R;     // B x 64, B x 32, B x 64 (what aggregate_pk / combine return)
+    uint8_t* transcript_status;          // B bytes: 0 = combine returns the signature; else the first share's failure
     uint32_t *tr_of, *d_words, *dpk, *e_pt, *a_words, *c_words;   // scratch: N, N x 8, N x 36, N x 36, B x 8, B x 8
     const uint32_t* tags;                // SAFE tags [JJS_LONG_TAGS][9]
     const uint32_t* comb_g;
@@ -119,9 +120,9 @@ JJS_HD void msig_final_item(const msig_params& P, uint32_t t) {
 // pass 5 (lane per participant): z_i*G + (c*d_i)*PK_i == E_i
 JJS_HD void msig_share_item(const msig_params& P, uint64_t i, uint32_t* ws) {
     const uint32_t t = P.tr_of[i];
-    const fe_src pk{P.PK, 64, 0}, zs{P.z, 32, 0}, rs{P.R, 64, 0}, ss{P.S, 64, 0};
+    const fe_src pk{P.PK, 64, 0}, zs{P.z, 32, 0}, rs{P.R, 64, 0}, ss{P.S, 64, 0}, ms{P.m, 32, 0};
     const words8 z = load_words(zs, i);
-    bool malformed = !words_lt(z, JJS_FR_WORDS);
+    bool malformed = !words_lt(z, JJS_FR_WORDS) || !words_lt(load_words(ms, t), JJS_Q_WORDS);
     for (int e = 0; e < 2; ++e) {
         malformed = malformed || !words_lt(load_words(pk, i, 32u * e), JJS_Q_WORDS) || !words_lt(load_words(rs, i, 32u * e), JJS_Q_WORDS) ||
                     !words_lt(load_words(ss, i, 32u * e), JJS_Q_WORDS);
@@ -135,6 +136,20 @@ JJS_HD void msig_share_item(const msig_params& P, uint64_t i, uint32_t* ws) {
     const ext_pt e = load_ext(P.e_pt + EXT_WORDS * i);
     const bool ok = fq_eq(fq_mul(lhs.x, e.z), fq_mul(e.x, lhs.z)) && fq_eq(fq_mul(lhs.y, e.z), fq_mul(e.y, lhs.z));
     P.share_status[i] = (uint8_t)(malformed ? (uint32_t)ST_MALFORMED : (ok ? (uint32_t)ST_OK : (uint32_t)ST_INVALID_SHARE));
+}
+
+// pass 6 (lane per transcript): what `combine` returns (src/multisig.rs:326-360): the signature only when every
+// share of the transcript verified; otherwise the status of the first failing share, and no signature -- the
+// outputs are cleared so that a caller who ignores the statuses cannot pick up an aggregate built from bad shares.
+JJS_HD void msig_verdict_item(const msig_params& P, uint32_t t) {
+    uint32_t st = ST_OK;
+    for (uint32_t i = P.offsets[t + 1]; i-- > P.offsets[t];) st = P.share_status[i] ? P.share_status[i] : st;
+    if (P.transcript_status) P.transcript_status[t] = (uint8_t)st;
+    if (st != ST_OK) {
+        store_words(P.sig_u, t, small_words(0));
+        store_words(P.sig_R, 2 * (uint64_t)t, small_words(0));
+        store_words(P.sig_R, 2 * (uint64_t)t + 1, small_words(0));
+    }
 }
 
 }  // namespace jjs

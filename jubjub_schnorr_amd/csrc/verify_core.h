@@ -174,13 +174,15 @@ JJS_HD uint32_t word_at(const words8& s, int j) {
 JJS_HD uint32_t nibble(const words8& s, int i) { return (word_at(s, i >> 3) >> ((i & 7) * 4)) & 15u; }
 // acc + (digit `w` of the recoded scalar) * P; `top` is the index of the unsigned top digit; `flip` adds
 // the opposite point (used for -b*R)
+// one_entry: profiling ablation only (JJS_SKIP bit 4, constant false in the product): every lookup reads entry 1
 JJS_HD ext_pt add_window(const ext_pt& acc, const uint32_t* tab, const words8& sc, int w, bool need_t, int top = 63,
-                         bool flip = false) {
+                         bool flip = false, bool one_entry = false) {
     uint32_t nib = nibble(sc, w);
     int d = (w == top) ? (int)nib : (int)nib - 8;
     bool neg = d < 0;
     uint32_t idx = (uint32_t)(neg ? -d : d);
     idx = idx > 8u ? 8u : idx;    // only an out-of-range (malformed, status 3) scalar gets here: stay inside the table
+    idx = one_entry ? 1u : idx;
     return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg != flip, need_t);
 }
 
@@ -574,11 +576,13 @@ JJS_HD bool point_on_curve_not_identity(const fe_n& u, const fe_n& v) {
 }
 
 // digit positions [lo, hi) of the comb; T of the result is valid only when t_last is set
-JJS_HD ext_pt add_comb_range(ext_pt acc, const uint32_t* comb, const words8& k, int lo, int hi, bool t_last) {
+JJS_HD ext_pt add_comb_range(ext_pt acc, const uint32_t* comb, const words8& k, int lo, int hi, bool t_last,
+                             bool one_entry = false) {
     for (int i = lo; i < hi; ++i) {
         constexpr int per_word = 32 / COMB_BITS;
-        const uint32_t digit = (word_at(k, i / per_word) >> ((i % per_word) * COMB_BITS)) & (uint32_t)(COMB_ENTRIES - 1);
-        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
+        uint32_t digit = (word_at(k, i / per_word) >> ((i % per_word) * COMB_BITS)) & (uint32_t)(COMB_ENTRIES - 1);
+        digit = one_entry ? 1u : digit;             // profiling ablation only: one cached row entry for every lane
+        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)(one_entry ? 0 : i) * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
         uint32_t w[COMB_ENTRY_WORDS];
 #pragma unroll
         for (int k4 = 0; k4 < COMB_ENTRY_WORDS / 4; ++k4) { u32x4 v = p[k4]; w[4 * k4] = v.x; w[4 * k4 + 1] = v.y; w[4 * k4 + 2] = v.z; w[4 * k4 + 3] = v.w; }
@@ -589,8 +593,8 @@ JJS_HD ext_pt add_comb_range(ext_pt acc, const uint32_t* comb, const words8& k, 
     }
     return acc;
 }
-JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k) {
-    return add_comb_range(acc, comb, k, 0, COMB_WINDOWS, false);
+JJS_HD ext_pt add_comb(ext_pt acc, const uint32_t* comb, const words8& k, bool one_entry = false) {
+    return add_comb_range(acc, comb, k, 0, COMB_WINDOWS, false, one_entry);
 }
 JJS_HD words8 widen128(const u128w& x) {
     words8 r;
@@ -646,7 +650,11 @@ JJS_HD words8 half_scalar_times_u(const half_scalars& h, const words8& u) {
 //    with R projectively.
 // Both cases run the same window loop (one copy of the doubling and addition code in the kernel).
 JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const words8& u, const words8& c,
-                           const half_scalars& h) {
+                           const half_scalars& h, const uint32_t* shared_tab = nullptr) {
+    // shared_tab: profiling ablation only (JJS_SKIP bit 4; nullptr in the product): every window / comb lookup of
+    // every lane reads entry 1 of this one table, i.e. always hits the cache -- what the lookups cost beyond that
+    // is the price of the gathers (results are then meaningless)
+    const bool one_entry = shared_tab != nullptr;
     const bool fixed = (E.comb != nullptr);
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {                       // table 0: PK; table 1: R (fixed) or Gen
@@ -680,11 +688,11 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
         for (int t = 0; t < 2; ++t) {
             const words8 sc = select_words(t == 0, s0, s1);
             const bool need_t = (t == 0) || (fixed && win == 0);      // comb additions follow the last window
-            acc = add_window(acc, ws + t * TABLE_WORDS, sc, win, need_t, top, t == 1 && flip1);
+            acc = add_window(acc, (one_entry ? shared_tab : ws) + t * TABLE_WORDS, sc, win, need_t, top, t == 1 && flip1, one_entry);
         }
     }
     if (fixed) {
-        acc = add_comb(acc, E.comb, w);
+        acc = add_comb(acc, E.comb, w, one_entry);
         return ext_is_identity(acc);
     }
     fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
@@ -781,7 +789,7 @@ JJS_HD uint32_t finish_item(const verify_params& P, uint64_t item, uint32_t* ws,
     const words8 u = load_words(P.u, item);
     bool eq_ok = true;
     const uint32_t n_eq = JJS_SKIP(P, 4u) ? 0u : P.n_eq;
-    for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, r.c, r.h) && eq_ok;
+    for (uint32_t k = 0; k < n_eq; ++k) eq_ok = check_equation(P.eq[k], item, ws, u, r.c, r.h, JJS_SKIP(P, 16u) ? P.workspace : nullptr) && eq_ok;
     if (r.malformed) return ST_MALFORMED;
     if (!r.valid) return ST_INVALID_POINT;
     if (JJS_SKIP(P, 1u)) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;

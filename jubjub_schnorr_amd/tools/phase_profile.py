@@ -19,6 +19,7 @@ def main():
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     _ffi.select_library(_ffi.PROFILING_LIB_PATH)      # the ablation switches exist only in the -DJJS_PROFILING build
     eng = jjs.engine()
+    _ffi.check(_ffi.lib().jjs_debug_force_path(1), "force_path")      # the throughput path is what is profiled
     arrays, _ = bench.make_inputs(eng, scheme, 1 << log2n, 0)
     call = [arrays[k] for k in bench.ARG_ORDER[scheme]]
 
@@ -45,6 +46,11 @@ def main():
     out["ms_challenge"] = out["ms_without_equations"] - out["ms_without_equations_and_challenge"]
     out["ms_equations"] = out["ms_without_validity"] - out["ms_without_validity_and_equations"]
     out["ms_euclid"] = out["ms_without_validity"] - out["ms_without_validity_and_euclid"]
+    # the gathers: window tables in a 340 MB workspace and comb rows in a 117 MB table, against every lookup hitting
+    # one cached entry (bit 4; point checks off in both runs so that no item goes through the resolve pass)
+    out["ms_without_validity_lookups_on_one_cached_entry"] = timed(1 | 16)
+    out["ms_gathers"] = out["ms_without_validity"] - out["ms_without_validity_lookups_on_one_cached_entry"]
+    _ffi.lib().jjs_debug_force_path(0)
     _ffi.lib().jjs_debug_skip_phases(0)
     print(json.dumps(out))
 

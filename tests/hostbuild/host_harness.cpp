@@ -213,13 +213,14 @@ int jjs_host_normalize(const uint8_t* const* ext, int k, size_t n, size_t lanes,
     return 0;
 }
 int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, const uint8_t* S, const uint8_t* m,
-                      const uint32_t* offsets, size_t B, uint8_t* status, uint8_t* agg_pk, uint8_t* sig_u, uint8_t* sig_R) {
+                      const uint32_t* offsets, size_t B, uint8_t* status, uint8_t* agg_pk, uint8_t* sig_u, uint8_t* sig_R,
+                      uint8_t* transcript_status) {
     ensure_tables();
     const size_t n = offsets[B];
     std::vector<uint32_t> tr(n), d(8 * n), dpk(EXT_WORDS * n), ept(EXT_WORDS * n), a(8 * B), c(8 * B), ws(WS_WORDS_PER_LANE + 4);
     msig_params P{};
     P.z = z; P.PK = PK; P.R = R; P.S = S; P.m = m; P.offsets = offsets; P.n_transcripts = (uint32_t)B; P.n_total = n;
-    P.share_status = status; P.agg_pk = agg_pk; P.sig_u = sig_u; P.sig_R = sig_R;
+    P.share_status = status; P.agg_pk = agg_pk; P.sig_u = sig_u; P.sig_R = sig_R; P.transcript_status = transcript_status;
     P.tr_of = tr.data(); P.d_words = d.data(); P.dpk = dpk.data(); P.e_pt = ept.data(); P.a_words = a.data(); P.c_words = c.data();
     P.tags = &JJS_SPONGE_TAG_LONG[0][0]; P.comb_g = g_comb_g.data();
     uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
@@ -229,6 +230,7 @@ int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, con
     for (size_t i = 0; i < n; ++i) msig_commit_item(P, i, w);
     for (size_t t = 0; t < B; ++t) msig_final_item(P, (uint32_t)t);
     for (size_t i = 0; i < n; ++i) msig_share_item(P, i, w);
+    for (size_t t = 0; t < B; ++t) msig_verdict_item(P, (uint32_t)t);
     return 0;
 }
 // raw entry points on arbitrary (un-normalised) limb vectors, for the bound-edge tests: n x 9 uint32 each

@@ -111,8 +111,9 @@ def multisig(z, PK, R, S, m, offsets):
     offs = np.ascontiguousarray(offsets, dtype=np.uint32)
     B, N = len(offs) - 1, len(z)
     status = np.empty(N, np.uint8); agg = np.empty((B, 64), np.uint8); su = np.empty((B, 32), np.uint8); sr = np.empty((B, 64), np.uint8)
-    load().jjs_host_multisig(_p(z), _p(PK), _p(R), _p(S), _p(m), _p(offs), ctypes.c_size_t(B), _p(status), _p(agg), _p(su), _p(sr))
-    return status, agg, su, sr
+    ts = np.empty(B, np.uint8)
+    load().jjs_host_multisig(_p(z), _p(PK), _p(R), _p(S), _p(m), _p(offs), ctypes.c_size_t(B), _p(status), _p(agg), _p(su), _p(sr), _p(ts))
+    return status, agg, su, sr, ts
 
 
 def _u32(a):

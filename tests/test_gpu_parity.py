@@ -457,12 +457,13 @@ def test_multisig_many_transcripts(eng):
     n = len(z)
     Z, P_, R_, S_, M = (np.tile(a, (reps, 1)) for a in (z, PK, R, S, m))
     offs_all = np.concatenate([[0]] + [offs[1:].astype(np.int64) + r * n for r in range(reps)]).astype(np.uint32)
-    st, agg, su, sr = (host(t) for t in eng.multisig_combine(dev(Z), dev(P_), dev(R_), dev(S_), dev(M), offs_all))
+    st, agg, su, sr, ts = (host(t) for t in eng.multisig_combine(dev(Z), dev(P_), dev(R_), dev(S_), dev(M), offs_all))
     assert (st.reshape(reps, n) == want[None, :]).all()
     assert (agg.reshape(reps, len(info), 64) == agg[:len(info)][None]).all()
     assert (sr.reshape(reps, len(info), 64) == sr[:len(info)][None]).all() and (su.reshape(reps, len(info), 32) == su[:len(info)][None]).all()
     for t, (a_pk, u, rsa) in enumerate(info):
-        assert su[t].tobytes() == o.le32(u)
+        bad = want[offs[t]:offs[t + 1]].any()
+        assert ts[t] == (4 if bad else 0) and su[t].tobytes() == (bytes(32) if bad else o.le32(u))
 
 
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])

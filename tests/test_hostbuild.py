@@ -203,21 +203,29 @@ def check_multisig(run, reference_kat):
     pks = [o.decompress(bytes.fromhex(x)) for x in k["public_keys"]]
     Rs = [o.decompress(bytes.fromhex(x)) for x in k["r_points"]]; Ss = [o.decompress(bytes.fromhex(x)) for x in k["s_points"]]
     z = np.stack([np.frombuffer(bytes.fromhex(x), np.uint8) for x in k["individual_shares"]])
-    st, agg, su, sr = run(z, pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
-    assert st.tolist() == [0, 0, 0]
+    st, agg, su, sr, ts = run(z, pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
+    assert st.tolist() == [0, 0, 0] and ts.tolist() == [0]
     from helpers import to_pt
     assert o.compress(to_pt(agg[0])).hex() == k["aggregate_public_key"]
     assert (su[0].tobytes() + o.compress(to_pt(sr[0]))).hex() == k["signature"]
     # swapped shares -> InvalidMultisigShare at those slots
-    st, *_ = run(z[[1, 0, 2]], pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
-    assert st.tolist() == [4, 4, 0]
+    st, _, su_bad, sr_bad, ts = run(z[[1, 0, 2]], pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([k["message"]]), [0, 3])
+    assert st.tolist() == [4, 4, 0] and ts.tolist() == [4]
+    # `combine` returns Err(InvalidMultisigShare), not a signature (src/multisig.rs:340-353): nothing to pick up
+    assert not su_bad.any() and not sr_bad.any()
+    # a non-canonical message makes every share of the transcript malformed
+    st, _, su_bad, sr_bad, ts = run(z, pt_arr(pks), pt_arr(Rs), pt_arr(Ss), fe_arr([o.Q]), [0, 3])
+    assert st.tolist() == [3, 3, 3] and ts.tolist() == [3] and not su_bad.any() and not sr_bad.any()
     # 2. random ragged transcripts
     z, PK, R, S, m, offs, want, info = make_multisig_batch(7, seed=9)
-    st, agg, su, sr = run(z, PK, R, S, m, offs)
+    st, agg, su, sr, ts = run(z, PK, R, S, m, offs)
     assert st.tolist() == want.tolist()
     for t, (a_pk, u, rsa) in enumerate(info):
-        assert agg[t].tobytes() == pt_bytes(a_pk).tobytes() and sr[t].tobytes() == pt_bytes(rsa).tobytes()
-        assert su[t].tobytes() == o.le32(u)
+        bad = want[offs[t]:offs[t + 1]].any()
+        assert ts[t] == (4 if bad else 0)
+        assert agg[t].tobytes() == pt_bytes(a_pk).tobytes()
+        assert sr[t].tobytes() == (bytes(64) if bad else pt_bytes(rsa).tobytes())
+        assert su[t].tobytes() == (bytes(32) if bad else o.le32(u))
 
 
 def test_multisig_batch(reference_kat):
