@@ -23,6 +23,7 @@
 #include "decode.h"
 #include "normalize.h"
 #include "small_batch.h"
+#include "key_tables.h"
 #include "sign_core.h"
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
@@ -41,8 +42,32 @@ __global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P) {
         store_prep(P.prep, P.n, item, prepare_item(P, item));
 }
 
+// What a first-pass lane does with its verdict: final statuses go to the caller's array and the tally (wave
+// ballots, one atomic per status per wave); undecided items (their points still need their own subgroup tests)
+// are appended to the queue of the resolve pass (one atomic per wave, entries of a wave contiguous).
+__device__ __forceinline__ void publish_status(const verify_params& P, uint64_t item, bool active, uint32_t st) {
+    if (active && st < ST_PENDING_EQ_FAILED && P.status) P.status[item] = (uint8_t)st;
+    if (P.tally) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            unsigned long long b = __ballot(active && st == k);
+            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
+        }
+    }
+    const bool pend = active && st >= ST_PENDING_EQ_FAILED;
+    const unsigned long long pmask = __ballot(pend);
+    if (pmask) {
+        const uint32_t lane = threadIdx.x & 63;
+        unsigned long long slot = 0;
+        if (lane == 0) slot = atomicAdd(P.pending_count, (unsigned long long)__popcll(pmask));
+        slot = __shfl(slot, 0);
+        if (pend) P.pending[slot + __popcll(pmask & ((1ull << lane) - 1ull))] = (item << 1) | (st == ST_PENDING_EQ_HELD ? 1u : 0u);
+    }
+}
+
 // second launch-bound argument: at least 2 waves per SIMD, i.e. at most 256 registers per lane
 __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
+    if (keyed_mode(P)) return;                   // this batch went down the key-table path (key_verify_kernel)
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     uint32_t* ws = P.workspace + gtid * WS_WORDS_PER_LANE;
@@ -50,26 +75,72 @@ __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
         const uint64_t item = base + gtid;
         const bool active = item < P.n;
         const uint64_t it = active ? item : P.n - 1;
-        const uint32_t st = finish_item(P, it, ws, load_prep(P.prep, P.n, it));
-        if (active && st < ST_PENDING_EQ_FAILED && P.status) P.status[item] = (uint8_t)st;
-        if (P.tally) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                unsigned long long b = __ballot(active && st == k);
-                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&P.tally[k], (unsigned long long)__popcll(b));
+        publish_status(P, item, active, finish_item(P, it, ws, load_prep(P.prep, P.n, it)));
+    }
+}
+
+// ---- key-table path (key_tables.h) ---------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {
+        for (uint32_t c = 0; c < K.n_cols; ++c) {
+            const key_column C = kt_col(K, (int32_t)c);
+            uint32_t slot = (uint32_t)kt_hash(C.src, item) & C.hash_mask;
+            for (;;) {                                     // every probe either claims a slot or meets a settled one
+                const uint32_t cur = atomicCAS(&C.hash[slot], 0u, (uint32_t)item + 1u);
+                if (cur == 0u) { C.rep[item] = (uint32_t)item; break; }
+                if (kt_same_key(C.src, item, cur - 1u)) { C.rep[item] = cur - 1u; break; }
+                slot = (slot + 1u) & C.hash_mask;          // the table has at least 2 n slots: never full
             }
         }
-        // items whose points still need their own subgroup tests: append to the queue of the resolve pass
-        // (one atomic per wave, entries of a wave contiguous)
-        const bool pend = active && st >= ST_PENDING_EQ_FAILED;
-        const unsigned long long pmask = __ballot(pend);
-        if (pmask) {
-            const uint32_t lane = threadIdx.x & 63;
-            unsigned long long slot = 0;
-            if (lane == 0) slot = atomicAdd(P.pending_count, (unsigned long long)__popcll(pmask));
-            slot = __shfl(slot, 0);
-            if (pend) P.pending[slot + __popcll(pmask & ((1ull << lane) - 1ull))] = (item << 1) | (st == ST_PENDING_EQ_HELD ? 1u : 0u);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void key_assign_kernel(key_params K) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {
+        for (uint32_t c = 0; c < K.n_cols; ++c) {
+            const key_column C = kt_col(K, (int32_t)c);
+            if (C.rep[item] != (uint32_t)item) continue;
+            const uint32_t id = atomicAdd(&K.counters[c], 1u);
+            C.keyid[item] = id;
+            if (id < K.max_keys) C.key_item[id] = (uint32_t)item;
         }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // the decision: enough signatures per key in every column
+        bool use = true;
+        for (uint32_t c = 0; c < K.n_cols; ++c) use = use && (uint64_t)K.counters[c] * KT_MIN_MULTIPLICITY <= K.n;
+        K.counters[2] = use ? 1u : 0u;
+    }
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
+        for (uint32_t c = 0; c < K.n_cols; ++c) {
+            const key_column C = kt_col(K, (int32_t)c);
+            const uint32_t r = C.rep[item];
+            if (r != (uint32_t)item) C.keyid[item] = C.keyid[r];      // r's own id was written by the previous launch
+        }
+}
+__global__ __launch_bounds__(BLOCK, 2) void key_chain_kernel(key_params K) {
+    if (!K.counters[2]) return;
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, c = t / K.max_keys, id = t % K.max_keys;
+    if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id);
+}
+__global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {
+    if (!K.counters[2]) return;
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t per_col = (uint64_t)K.max_keys * KT_POSITIONS;
+    const uint32_t c = (uint32_t)(t / per_col), id = (uint32_t)((t % per_col) / KT_POSITIONS), pos = (uint32_t)(t % KT_POSITIONS);
+    if (c < K.n_cols && id < K.counters[c]) kt_table_lane(kt_col(K, (int32_t)c), id, pos);
+}
+__global__ __launch_bounds__(BLOCK, 2) void key_verify_kernel(verify_params P, key_params K) {
+    if (!keyed_mode(P)) return;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t base = 0; base < P.n; base += total) {
+        const uint64_t item = base + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        const bool active = item < P.n;
+        const uint64_t it = active ? item : P.n - 1;
+        publish_status(P, item, active, kt_finish_item(P, K, it, load_prep(P.prep, P.n, it)));
     }
 }
 
@@ -338,6 +409,8 @@ struct call_slot {
     size_t wire_items = 0;
     uint8_t* small = nullptr;         // latency path: window tables of the chain lanes + per-point verdicts (grow-only)
     size_t small_bytes = 0;
+    uint8_t* keys = nullptr;          // key-table path: hash tables, key ids, bases and window tables per key (grow-only)
+    size_t keys_bytes = 0;
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
 };
 constexpr int N_SMALL_SLOTS = 3;
@@ -357,7 +430,7 @@ struct device_state {
     uint32_t* comb_gn = nullptr;
     uint8_t* tag = nullptr;
     unsigned long long* tally = nullptr;
-    int grid_sign = 0, grid_resolve = 0, grid_prepare = 0;
+    int grid_sign = 0, grid_resolve = 0, grid_prepare = 0, grid_key_verify = 0;
     hipEvent_t last_use = nullptr;  // host-buffer calls: end of the last use of the staging arena and the counters
     uint32_t* dlog_pow = nullptr;  // square-root tables (decode.h)
     uint8_t* dlog_hash = nullptr;
@@ -365,6 +438,8 @@ struct device_state {
     uint8_t* msig = nullptr;       // multisig scratch
     size_t msig_items = 0, msig_transcripts = 0;
     int grid_msig = 0;
+    hipStream_t key_stream = nullptr;    // key-table path: the per-key kernels run here, beside the challenge hashes
+    hipEvent_t key_fork = nullptr, key_join = nullptr;
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
@@ -515,6 +590,61 @@ int launch_small(verify_params P, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }
+int ensure_keys(size_t bytes) {
+    if (bytes <= sl->keys_bytes) return JJS_OK;
+    if (sl->keys) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(sl->keys));
+        sl->keys = nullptr; sl->keys_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&sl->keys, bytes));
+    sl->keys_bytes = bytes;
+    return JJS_OK;
+}
+// Large batches in the big slot only: the per-key tables are sized for n / KT_MIN_MULTIPLICITY keys per column.
+constexpr size_t KT_MIN_ITEMS = 65536;
+bool key_path_applies(const verify_params& P) {
+#if defined(JJS_PROFILING)
+    if (g_force_path == 3) return false;           // throughput path without the key tables
+#endif
+    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && sl == &g->slots[0] && P.n_eq >= 1;
+}
+// Carves the key buffers of this call out of the slot's arena and clears the hash tables and counters.
+int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
+    K.n = P.n;
+    K.max_keys = (uint32_t)(P.n / KT_MIN_MULTIPLICITY);
+    // key columns: PK of every equation, and the generator where it is per-item data
+    fe_src cols[2];
+    uint32_t n_cols = 0;
+    for (uint32_t e = 0; e < P.n_eq; ++e) {
+        cols[P.eq[e].pk_col] = P.eq[e].pk; n_cols = n_cols > (uint32_t)P.eq[e].pk_col + 1 ? n_cols : (uint32_t)P.eq[e].pk_col + 1;
+        if (!P.eq[e].comb) { cols[P.eq[e].gen_col] = P.eq[e].gen; n_cols = n_cols > (uint32_t)P.eq[e].gen_col + 1 ? n_cols : (uint32_t)P.eq[e].gen_col + 1; }
+    }
+    K.n_cols = n_cols;
+    size_t slots = 1;
+    while (slots < 2 * P.n) slots <<= 1;
+    auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + pad(K.max_keys) +
+                           pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4) + pad((size_t)K.max_keys * KT_POSITIONS * TABLE_WORDS * 4);
+    if (int rc = ensure_keys(256 + n_cols * per_col)) return rc;
+    uint8_t* p = sl->keys;
+    K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
+    HIP_TRY(hipMemsetAsync(K.counters, 0, 256, s));
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        key_column& C = K.col[c];
+        C.src = cols[c];
+        C.hash = reinterpret_cast<uint32_t*>(p); C.hash_mask = (uint32_t)(slots - 1); p += pad(slots * 4);
+        HIP_TRY(hipMemsetAsync(C.hash, 0, slots * 4, s));
+        C.rep = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
+        C.keyid = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
+        C.key_item = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * 4);
+        C.key_flags = p; p += pad(K.max_keys);
+        C.bases = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4);
+        C.tables = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * TABLE_WORDS * 4);
+    }
+    return JJS_OK;
+}
+
 bool small_path_applies(const verify_params& P) {
     if (P.n_eq < 1 || P.n_eq > 2) return false;
     for (uint32_t k = 0; k < P.n_eq; ++k)
@@ -547,7 +677,29 @@ int launch_verify(verify_params P, hipStream_t s) {
     P.pending_count = reinterpret_cast<unsigned long long*>(sl->pending);
     P.pending = sl->pending + 2;
     HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
+    key_params K{};
+    const bool try_keys = key_path_applies(P);
+    if (try_keys) {
+        // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
+        // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
+        if (int rc = setup_keys(P, K, s)) return rc;
+        const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
+        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
+        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
+        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
+        HIP_TRY(hipEventRecord(g->key_fork, s));
+        HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
+        hipLaunchKernelGGL(key_chain_kernel, dim3((K.n_cols * K.max_keys + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, g->key_stream, K);
+        hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_POSITIONS + BLOCK - 1) / BLOCK)),
+                           dim3(BLOCK), 0, g->key_stream, K);
+        HIP_TRY(hipEventRecord(g->key_join, g->key_stream));
+        P.key_flag = K.counters + 2;
+    }
     hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P);
+    if (try_keys) {
+        HIP_TRY(hipStreamWaitEvent(s, g->key_join, 0));
+        hipLaunchKernelGGL(key_verify_kernel, dim3(grid_for(g->grid_key_verify, P.n)), dim3(BLOCK), 0, s, P, K);
+    }
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(sl->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(g->grid_resolve, P.n * P.resolve_lanes)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
@@ -584,6 +736,9 @@ int init_device(device_state& d, int ordinal) {
     HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d.key_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.key_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.key_join, hipEventDisableTiming));
     for (int i = 0; i < 33; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_up[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_done[i], hipEventDisableTiming));
@@ -594,6 +749,9 @@ int init_device(device_state& d, int ordinal) {
     int per_cu_p = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, prepare_kernel, BLOCK, 0));
     d.grid_prepare = prop.multiProcessorCount * (per_cu_p < 1 ? 1 : per_cu_p) * 4;   // not persistent: a few blocks per slot
+    int per_cu_k = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_k, key_verify_kernel, BLOCK, 0));
+    d.grid_key_verify = prop.multiProcessorCount * (per_cu_k < 1 ? 1 : per_cu_k) * 4;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, resolve_kernel, BLOCK, 0));
     d.grid_resolve = prop.multiProcessorCount * (per_cu_r < 1 ? 1 : per_cu_r);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, verify_kernel, BLOCK, 0));
@@ -644,7 +802,7 @@ void free_device(device_state& d) {
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (call_slot& c : d.slots) {
-        void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small};
+        void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small, c.keys};
         for (void* b : sb)
             if (b) (void)hipFree(b);
         if (c.last_use) (void)hipEventDestroy(c.last_use);
@@ -656,6 +814,9 @@ void free_device(device_state& d) {
         if (d.chunk_done[i]) (void)hipEventDestroy(d.chunk_done[i]);
     }
     if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
+    if (d.key_stream) { (void)hipStreamSynchronize(d.key_stream); (void)hipStreamDestroy(d.key_stream); }
+    if (d.key_fork) (void)hipEventDestroy(d.key_fork);
+    if (d.key_join) (void)hipEventDestroy(d.key_join);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = device_state{};
 }

@@ -1,0 +1,184 @@
+// Key-table path: batches in which public keys (and per-key generators) repeat.
+//
+// The throughput path treats every public key as a fresh variable point: per signature it builds window tables
+// for PK and R and runs 124 shared doublings (verify_core.h check_equation).  When a batch carries many
+// signatures under the same key -- a validator set, an account signing many messages; SURVEY.md 8(d)'s workload
+// has 4 096 keys under 2^20 signatures -- the key can be given what the generators G, G' have: a table of all its
+// window multiples, built once per call, after which c*PK costs additions only.  Per call, on the device:
+//
+//   1. dedup      every key column (PK; PK' for the double scheme; PK and Gen for the per-item generator) is
+//                 deduplicated by its 64 bytes in an open-addressing hash table (full byte comparison on a hash
+//                 hit: two keys are merged only if they are the same bytes); keys get dense ids.
+//   2. decision   if some column has more than n / KT_MIN_MULTIPLICITY distinct keys the tables would cost more
+//                 than they save: a device flag sends the batch down the throughput path instead (both sets of
+//                 kernels are queued, the one that is not wanted leaves at once; no host synchronisation).
+//   3. per key    `is_valid` of the key point ONCE per key (src/keys/public.rs:159-164: canonical, on the curve,
+//                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(4i) * P, i = 0..63, and
+//                 the tables {0..8} * B_i (signed 4-bit digits, as recode_signed4 produces them).
+//   4. per item   challenge hash as before (prepare_item in keyed mode: no half-size scalars, no combined test);
+//                 then  acc = sum_i digit_i(c) * B_i  (64 additions, no doubling) + u*G from the fixed-base comb
+//                 (16 additions), compared with R projectively: the reference's own equation u*G + c*PK == R
+//                 (src/keys/public.rs:128-130), computed exactly by the complete addition law.
+//   Subgroup membership of R: if the equation holds and the key is torsion-free then R = u*G + c*PK is in the
+//   prime-order subgroup, and R != identity, on-curve are checked per item; if it fails, R's own test decides
+//   between InvalidPoint and InvalidSignature in the resolve pass (as for the per-item generator scheme).
+//
+// ~330 k instructions per single verification instead of ~600 k, plus ~23 k wave-instructions per distinct key.
+#pragma once
+#include "verify_core.h"
+
+namespace jjs {
+
+constexpr int KT_POSITIONS = 64;                 // signed 4-bit digits of a scalar below 2^252
+constexpr uint32_t KT_MIN_MULTIPLICITY = 16;     // the tables pay from ~6 signatures per key; margin for their memory
+constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
+constexpr int KT_BASE_WORDS = 36;
+
+struct key_column {
+    fe_src src;              // the key points in the caller's arrays (64 B affine, u || v)
+    uint32_t* hash;          // open addressing, hash_mask + 1 slots: 0 = empty, else item index + 1
+    uint32_t hash_mask;
+    uint32_t pad_;
+    uint32_t* rep;           // [n] first item found with the same key bytes
+    uint32_t* keyid;         // [n] dense id of the item's key
+    uint32_t* key_item;      // [max_keys] representative item of a key
+    uint8_t* key_flags;      // [max_keys] KT_KEY_*
+    uint32_t* bases;         // [max_keys][KT_POSITIONS][36]: 2^(4i) * P in extended coordinates
+    uint32_t* tables;        // [max_keys][KT_POSITIONS][TABLE_WORDS]: {0..8} * 2^(4i) * P, cached-addend form
+};
+struct key_params {
+    uint32_t n_cols, max_keys;
+    key_column col[2];
+    uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 1 = key-table path
+    uint64_t n;
+};
+
+// column `idx` (0 or 1) of K, chosen field by field: indexing the kernel-argument struct with a run-time index
+// would make the compiler copy it to scratch memory
+JJS_HD key_column kt_col(const key_params& K, int32_t idx) {
+    const key_column &a = K.col[0], &b = K.col[1];
+    const bool z = idx == 0;
+    key_column c;
+    c.src.base = z ? a.src.base : b.src.base; c.src.stride = z ? a.src.stride : b.src.stride; c.src.off = z ? a.src.off : b.src.off;
+    c.hash = z ? a.hash : b.hash; c.hash_mask = z ? a.hash_mask : b.hash_mask; c.pad_ = 0;
+    c.rep = z ? a.rep : b.rep; c.keyid = z ? a.keyid : b.keyid; c.key_item = z ? a.key_item : b.key_item;
+    c.key_flags = z ? a.key_flags : b.key_flags; c.bases = z ? a.bases : b.bases; c.tables = z ? a.tables : b.tables;
+    return c;
+}
+
+JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (uint32_t off = 0; off < 64; off += 32) {
+        const words8 w = load_words(src, item, off);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            h ^= ((uint64_t)w.w[i + 1] << 32) | w.w[i];
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+        }
+    }
+    return h;
+}
+JJS_HD bool kt_same_key(const fe_src& src, uint64_t a, uint64_t b) {
+    uint32_t diff = 0;
+#pragma unroll
+    for (uint32_t off = 0; off < 64; off += 32) {
+        const words8 x = load_words(src, a, off), y = load_words(src, b, off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) diff |= x.w[i] ^ y.w[i];
+    }
+    return diff == 0;
+}
+
+JJS_HD uint32_t* kt_base(const key_column& C, uint32_t id, uint32_t pos) {
+    return C.bases + ((size_t)id * KT_POSITIONS + pos) * KT_BASE_WORDS;
+}
+JJS_HD uint32_t* kt_table(const key_column& C, uint32_t id, uint32_t pos) {
+    return C.tables + ((size_t)id * KT_POSITIONS + pos) * TABLE_WORDS;
+}
+JJS_HD void kt_store_ext(uint32_t* dst, const ext_pt& p) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { dst[i] = p.x.l[i]; dst[9 + i] = p.y.l[i]; dst[18 + i] = p.z.l[i]; dst[27 + i] = p.t.l[i]; }
+}
+JJS_HD ext_pt kt_load_ext(const uint32_t* src) {
+    ext_pt p;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { p.x.l[i] = src[i]; p.y.l[i] = src[9 + i]; p.z.l[i] = src[18 + i]; p.t.l[i] = src[27 + i]; }
+    return p;
+}
+
+// one key: `is_valid` of its point, and the chain of bases
+JJS_HD void kt_chain_key(const key_column& C, uint32_t id) {
+    const uint64_t item = C.key_item[id];
+    const words8 uw = load_words(C.src, item), vw = load_words(C.src, item, 32);
+    const bool canonical = words_lt(uw, JJS_Q_WORDS) && words_lt(vw, JJS_Q_WORDS);
+    const fe_n pu = fq_from_words(uw), pv = fq_from_words(vw);
+    const bool valid = canonical && point_on_curve_not_identity(pu, pv) && is_torsion_free(pu, pv);
+    C.key_flags[id] = (uint8_t)((canonical ? 0u : KT_KEY_MALFORMED) | (valid ? KT_KEY_VALID : 0u));
+    ext_pt p = ext_from_affine(pu, pv);
+    kt_store_ext(kt_base(C, id, 0), p);
+    for (uint32_t pos = 1; pos < (uint32_t)KT_POSITIONS; ++pos) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) p = ext_double(p, j == 3);
+        kt_store_ext(kt_base(C, id, pos), p);
+    }
+}
+
+// table[j] = j * P for j = 0..8, P in extended coordinates (the cached-addend entries keep their Z)
+JJS_HD void kt_build_table(uint32_t* tab, const ext_pt& p1) {
+    const niels_pt n1 = to_niels(p1);
+    store_niels(tab, niels_identity());
+    store_niels(tab + ENTRY_WORDS, n1);
+    ext_pt acc = ext_double(p1, true);
+    store_niels(tab + 2 * ENTRY_WORDS, to_niels(acc));
+    for (int j = 3; j <= 8; ++j) {
+        acc = ext_add_niels(acc, n1, false, true);
+        store_niels(tab + j * ENTRY_WORDS, to_niels(acc));
+    }
+}
+JJS_HD void kt_table_lane(const key_column& C, uint32_t id, uint32_t pos) {
+    kt_build_table(kt_table(C, id, pos), kt_load_ext(kt_base(C, id, pos)));
+}
+
+// acc + s * P for the key `id` of column C, s < 2^252: 64 additions, no doubling.  T of the result is valid.
+JJS_HD ext_pt kt_add_scalar(ext_pt acc, const key_column& C, uint32_t id, const words8& s) {
+    const words8 sc = recode_signed4(s);
+    for (int pos = KT_POSITIONS - 1; pos >= 0; --pos) acc = add_window(acc, kt_table(C, id, (uint32_t)pos), sc, pos, true, 63, false);
+    return acc;
+}
+
+// The equations of one item through the key tables (step 4 above).  r = prepare_item's record in keyed mode:
+// challenge, malformed (u, m, the R points), valid (every R point on the curve and not the identity).
+JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint64_t item, const prep_record& r) {
+    const words8 u = load_words(P.u, item);
+    bool keys_valid = true, keys_malformed = false, eq_ok = true;
+    for (uint32_t e = 0; e < P.n_eq; ++e) {
+        const eq_desc& E = P.eq[e];
+        ext_pt acc = ext_identity();
+        {
+            const key_column C = kt_col(K, E.pk_col);
+            const uint32_t id = C.keyid[item], f = C.key_flags[id];
+            keys_valid = keys_valid && (f & KT_KEY_VALID) != 0;
+            keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
+            acc = kt_add_scalar(acc, C, id, r.c);                             // c * PK
+        }
+        if (E.comb) {
+            acc = add_comb(acc, E.comb, u);                                   // + u * G (G')
+        } else {
+            const key_column C = kt_col(K, E.gen_col);
+            const uint32_t id = C.keyid[item], f = C.key_flags[id];
+            keys_valid = keys_valid && (f & KT_KEY_VALID) != 0;
+            keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
+            acc = kt_add_scalar(acc, C, id, u);                               // + u * Gen
+        }
+        const fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
+        eq_ok = ext_eq_affine(acc, ru, rv) && eq_ok;
+    }
+    if (r.malformed || keys_malformed) return ST_MALFORMED;
+    if (!r.valid || !keys_valid) return ST_INVALID_POINT;
+    // the equations hold: every R is a sum of torsion-free points; they fail: R's own subgroup test decides
+    return eq_ok ? ST_OK : ST_PENDING_EQ_FAILED;
+}
+
+}  // namespace jjs

@@ -29,7 +29,8 @@ inline verify_params params_single(const uint8_t* u, const uint8_t* R, const uin
     P.hash_in[4] = fe32_src(m);
     P.points[0] = pt_src(PK); P.points[1] = pt_src(R);
     P.resolve_lanes = 2;
-    P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R)};
+    P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R), 0, -1};
+    P.key_points_mask = 1u;          // points[0] = PK
     P.u = fe32_src(u);
     P.n = n; P.status = o.status; P.tally = o.tally; P.c_out = o.c_out; P.workspace = o.workspace;
     return P;
@@ -48,8 +49,9 @@ inline verify_params params_double(const uint8_t* u, const uint8_t* R, const uin
     P.hash_in[9] = fe32_src(m);
     P.points[0] = pt_src(PK); P.points[1] = pt_src(PKp); P.points[2] = pt_src(R); P.points[3] = pt_src(Rp);
     P.resolve_lanes = 4;
-    P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R)};
-    P.eq[1] = eq_desc{comb_gn, fe_src{nullptr, 0, 0}, pt_src(PKp), pt_src(Rp)};
+    P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R), 0, -1};
+    P.eq[1] = eq_desc{comb_gn, fe_src{nullptr, 0, 0}, pt_src(PKp), pt_src(Rp), 1, -1};
+    P.key_points_mask = 3u;          // points[0] = PK, points[1] = PK'
     P.u = fe32_src(u);
     P.n = n; P.status = o.status; P.tally = o.tally; P.c_out = o.c_out; P.workspace = o.workspace;
     return P;
@@ -66,7 +68,8 @@ inline verify_params params_vargen(const uint8_t* u, const uint8_t* R, const uin
     P.points[0] = pt_src(PK); P.points[1] = pt_src(Gen); P.points[2] = pt_src(R);
     P.own_test_mask = 3u;            // PK and Gen are tested on their own; R rides on the equation
     P.resolve_lanes = 1;
-    P.eq[0] = eq_desc{nullptr, pt_src(Gen), pt_src(PK), pt_src(R)};
+    P.eq[0] = eq_desc{nullptr, pt_src(Gen), pt_src(PK), pt_src(R), 0, 1};
+    P.key_points_mask = 3u;          // points[0] = PK, points[1] = Gen
     P.u = fe32_src(u);
     P.n = n; P.status = o.status; P.tally = o.tally; P.c_out = o.c_out; P.workspace = o.workspace;
     return P;

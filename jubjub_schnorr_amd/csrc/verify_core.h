@@ -45,6 +45,7 @@ struct eq_desc {           // u*Gen + c*PK == R
     fe_src gen;            // affine generator (u at off, v at off+32); used when comb == nullptr
     fe_src pk;
     fe_src r;
+    int32_t pk_col, gen_col;   // key-table path (key_tables.h): which deduplicated key column PK / Gen is (-1: none)
 };
 struct verify_params {
     uint32_t n_hash, n_points, n_eq;
@@ -66,6 +67,8 @@ struct verify_params {
     uint32_t own_test_mask;          // bit k: points[k] gets its own subgroup test in the first pass
     uint32_t resolve_lanes;          // lanes per queued item in the resolve pass: 1, 2 or 4 >= points left to test
     uint32_t decoded_points;         // non-zero: every point was produced by decompress_point (on the curve)
+    uint32_t key_points_mask;        // bit k: points[k] is a key column of the key-table path (validated once per key)
+    const uint32_t* key_flag;        // device word, non-zero when this batch runs the key-table path (key_tables.h), or nullptr
     uint32_t small_mode;             // non-zero: latency path (small_batch.h): prepare_item leaves every point check to the
                                      // per-point lanes of that path and runs no subgroup test itself
     uint8_t* prep;                   // 65 n bytes: what prepare_kernel hands to verify_kernel (see prep_record)
@@ -736,8 +739,12 @@ struct prep_record {
     bool proven;         // every combined subgroup test passed
 };
 
+// Does this batch run the key-table path?  Decided on the device after the keys have been counted.
+JJS_HD bool keyed_mode(const verify_params& P) { return P.key_flag != nullptr && *P.key_flag != 0u; }
+
 JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true) {
     prep_record r;
+    const bool keyed = keyed_mode(P);
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
     bool malformed = !words_lt(u, JJS_FR_WORDS);
@@ -749,6 +756,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     const bool check_points = !JJS_SKIP(P, 1u) && !P.small_mode;
     bool valid = true;
     for (uint32_t k = 0; k < (check_points ? P.n_points : 0u); ++k) {
+        if (keyed && ((P.key_points_mask >> k) & 1u)) continue;      // a key: validated once per key, not per item
         fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
         // points that come out of the wire decoder satisfy the curve equation by construction
         valid = (P.decoded_points ? !affine_is_identity(pu, pv) : point_on_curve_not_identity(pu, pv)) && valid;
@@ -766,7 +774,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     r.c = c;
 
     // 4. half-size scalars (shared by both equations of the double scheme) and the combined subgroup tests
-    const uint32_t n_eq = JJS_SKIP(P, 4u) ? 0u : P.n_eq;
+    const uint32_t n_eq = (JJS_SKIP(P, 4u) || keyed) ? 0u : P.n_eq;     // the key-table path needs neither
     half_scalars h{};
     if (n_eq && P.eq[0].comb) {
         if (JJS_SKIP(P, 8u)) {                           // profiling only: stand-in scalars, no Euclid
@@ -831,8 +839,9 @@ JJS_HD bool resolve_point(const verify_params& P, uint64_t item, uint32_t j) {
     fe_src src = P.points[0];
     bool found = false;
     uint32_t seen = 0;
+    const uint32_t tested = P.own_test_mask | (keyed_mode(P) ? P.key_points_mask : 0u);
     for (uint32_t k = 0; k < P.n_points; ++k) {
-        if ((P.own_test_mask >> k) & 1u) continue;
+        if ((tested >> k) & 1u) continue;
         const bool hit = (seen++ == j);
         src.base = hit ? P.points[k].base : src.base;
         src.stride = hit ? P.points[k].stride : src.stride;

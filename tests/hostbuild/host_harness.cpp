@@ -8,6 +8,9 @@
 #include "decode.h"
 #include "normalize.h"
 #include "small_batch.h"
+#include "key_tables.h"
+#include <map>
+#include <string>
 #include "multisig_core.h"
 #include "jjs_sponge_tags_long.inc"
 
@@ -89,7 +92,78 @@ static void run_small(verify_params P, uint32_t positions) {
     }
 }
 
+// the key-table path of csrc/key_tables.h: keys deduplicated with a std::map (the device uses a hash table with
+// the same byte-exact notion of "same key"), everything else through the product's own functions
+static void run_keyed(verify_params P) {
+    key_params K{};
+    K.n = P.n; K.max_keys = (uint32_t)P.n + 1;
+    fe_src cols[2]; uint32_t n_cols = 0;
+    for (uint32_t e = 0; e < P.n_eq; ++e) {
+        cols[P.eq[e].pk_col] = P.eq[e].pk; n_cols = std::max(n_cols, (uint32_t)P.eq[e].pk_col + 1);
+        if (!P.eq[e].comb) { cols[P.eq[e].gen_col] = P.eq[e].gen; n_cols = std::max(n_cols, (uint32_t)P.eq[e].gen_col + 1); }
+    }
+    K.n_cols = n_cols;
+    std::vector<uint32_t> counters(64, 0), keyid[2], key_item[2], bases[2], tables[2];
+    std::vector<uint8_t> flags[2];
+    K.counters = counters.data();
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        key_column& C = K.col[c];
+        C.src = cols[c];
+        keyid[c].resize(P.n + 1);
+        std::map<std::string, uint32_t> seen;
+        for (uint64_t i = 0; i < P.n; ++i) {
+            std::string key((const char*)(C.src.base + i * C.src.stride + C.src.off), 64);
+            auto it = seen.find(key);
+            if (it == seen.end()) { it = seen.emplace(key, (uint32_t)seen.size()).first; key_item[c].push_back((uint32_t)i); }
+            keyid[c][i] = it->second;
+        }
+        const size_t nk = key_item[c].size();
+        counters[c] = (uint32_t)nk;
+        flags[c].resize(nk + 1); bases[c].resize(nk * KT_POSITIONS * KT_BASE_WORDS + 4); tables[c].resize(nk * KT_POSITIONS * TABLE_WORDS + 8);
+        C.keyid = keyid[c].data(); C.key_item = key_item[c].data(); C.key_flags = flags[c].data();
+        C.bases = bases[c].data();
+        C.tables = (uint32_t*)(((uintptr_t)tables[c].data() + 15) & ~(uintptr_t)15);
+        for (uint32_t id = 0; id < nk; ++id) {
+            kt_chain_key(C, id);
+            for (uint32_t pos = 0; pos < (uint32_t)KT_POSITIONS; ++pos) kt_table_lane(C, id, pos);
+        }
+    }
+    counters[2] = 1;
+    P.key_flag = &counters[2];
+    for (uint64_t i = 0; i < P.n; ++i) {
+        uint32_t st = kt_finish_item(P, K, i, prepare_item(P, i));
+        if (st >= ST_PENDING_EQ_FAILED) st = resolve_item(P, i, st == ST_PENDING_EQ_HELD);
+        if (P.status) P.status[i] = (uint8_t)st;
+        if (P.tally) P.tally[st]++;
+    }
+}
+
 extern "C" {
+
+int jjs_host_verify_keyed_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                                 uint8_t* status, uint64_t* tally) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_keyed(params_single(u, R, PK, m, n, g_comb_g.data(), out_ptrs{status, t, nullptr, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+int jjs_host_verify_keyed_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                                 const uint8_t* m, size_t n, uint8_t* status, uint64_t* tally) {
+    ensure_tables();
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_keyed(params_double(u, R, Rp, PK, PKp, m, n, (const uint8_t*)g_tag, g_comb_g.data(), g_comb_gn.data(),
+                            out_ptrs{status, t, nullptr, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+int jjs_host_verify_keyed_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                                 size_t n, uint8_t* status, uint64_t* tally) {
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_keyed(params_vargen(u, R, PK, Gen, m, n, out_ptrs{status, t, nullptr, nullptr}));
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
 
 int jjs_host_verify_small_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                                  uint8_t* status, uint64_t* tally, int positions) {

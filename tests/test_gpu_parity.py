@@ -496,6 +496,40 @@ def test_differential_32k_against_c_oracle(eng, scheme):
     assert set(want.tolist()) == {0, 1, 2, 3}
 
 
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_key_table_path_against_oracle(eng, scheme):
+    """2^17 items under 512 keys: the engine deduplicates the keys, builds per-key tables and verifies with additions
+    only (csrc/key_tables.h).  Every status against the C oracle, with invalid keys shared by many items (identity,
+    order 2, mixed order), wrong keys, tampered messages, small-order components on R and non-canonical scalars."""
+    n = 1 << 17
+    b = make_batch(scheme, n, seed=9090, n_keys=512)
+    t8 = torsion_generator()
+    rng = np.random.default_rng(16)
+    from helpers import pt_bytes, to_pt
+    for k in range(1, 8):
+        i = int(rng.integers(0, n))
+        b["R"][i] = pt_bytes(o.add(to_pt(b["R"][i]), o.mul(t8, k)))
+    for i in rng.integers(0, n, 8):
+        b["R"][i, 32] ^= 1                       # R off the curve
+    for i in rng.integers(0, n, 4):
+        b["u"][i] = 0xFF
+    b["PK"][5, :32] = fe_bytes(o.Q)              # a non-canonical key
+    b["R"][9] = pt_bytes(o.IDENTITY)
+    want = oracle_verify(scheme, b)
+    st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
+    got = host(st)
+    assert (got == want).all(), np.where(got != want)[0][:10]
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    assert set(want.tolist()) == {0, 1, 2, 3}
+    # the same items with every key made distinct in its bytes is impossible without re-signing; instead check the
+    # fall-back decision: 2^16 items under 2^16 / 8 keys (8 per key: below the threshold) still verify the same
+    m = 1 << 16
+    sel = np.concatenate([np.arange(i, n, 512)[:8] for i in range(512)] * 16)[:m]
+    sub = {k: v[sel] for k, v in b.items()}
+    st2, _ = eng.verify(scheme, *[dev(sub[k]) for k in ARG_ORDER[scheme]])
+    assert (host(st2) == want[sel]).all()
+
+
 def test_both_paths_at_every_size():
     """Throughput path and latency path forced in turn (profiling build, child process) on ragged sizes, edge
     cases and the torsion grid."""
