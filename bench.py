@@ -43,10 +43,12 @@ ARG_ORDER = {"single": ["u", "R", "PK", "m"], "double": ["u", "R", "Rp", "PK", "
              "vargen": ["u", "R", "PK", "Gen", "m"]}
 
 
-def make_inputs(eng, scheme: str, n: int, rank: int):
-    """Returns (dict of CUDA uint8 tensors, expected status tensor)."""
+def make_inputs(eng, scheme: str, n: int, rank: int, n_keys: int = N_KEYS):
+    """Returns (dict of CUDA uint8 tensors, expected status tensor).  n_keys: distinct key pairs (SURVEY.md 8d: 4 096;
+    n_keys = n gives every signature its own key)."""
     import torch
     gen = torch.Generator(device="cpu").manual_seed(SEED + 7919 * rank)
+    N_KEYS = max(2, min(int(n_keys), n))         # noqa: N806  (shadows the module default on purpose)
 
     def rand_bytes(rows, top_mask):
         t = torch.randint(0, 256, (rows, 32), dtype=torch.uint8, generator=gen)
@@ -245,12 +247,12 @@ def workload_name(scheme: str, n: int, world: int) -> str:
     return f"2^{lg} {scheme} signatures per GPU, resident in HBM{exact}(BASELINE.json configs[{cfg}] per GPU)"
 
 
-def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with_cpu: bool):
+def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with_cpu: bool, n_keys: int = N_KEYS):
     """W warm-up steps, then exactly K timed steps between two barrier + synchronize fences; returns the record of
     this scheme (rank 0) and whether every bit-exact check held (every rank)."""
     import torch
     from jubjub_schnorr_amd.sharding import allreduce_tally
-    arrays, expect = make_inputs(eng, scheme, n, rank)
+    arrays, expect = make_inputs(eng, scheme, n, rank, n_keys)
     call = [arrays[k] for k in ARG_ORDER[scheme]]
     if args.wire:
         c = {k: eng.compress(v) for k, v in arrays.items() if v.shape[1] == 64}
@@ -324,7 +326,7 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     algo_bytes = WIRE_BYTES[scheme] if args.wire else (EXT_BYTES[scheme] if args.ext else ALGO_BYTES[scheme])
     achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
     traffic, alu = None, None
-    pmc = None if (args.wire or args.ext) else committed_pmc(scheme, n)
+    pmc = None if (args.wire or args.ext or n_keys != N_KEYS) else committed_pmc(scheme, n)
     if pmc:
         traffic = pmc.get("hbm_bytes_per_launch")
         # the binding roofline: VALU issue.  Instruction count per launch from the committed PMC pass
@@ -342,11 +344,14 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
         "ms_per_step": elapsed / args.steps * 1e3,
         "workload": workload_name(scheme, n, world),
         "items_per_gpu": n,
+        "distinct_keys_per_gpu": min(n_keys, n),
         "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes * n,
-                     "kernel": ("decode_kernel + " if args.wire else "normalize_kernel + " if args.ext else "") + "prepare_kernel + verify_kernel + resolve_kernel (one batch)",
+                     "kernel": ("decode_kernel + " if args.wire else "normalize_kernel + " if args.ext else "") +
+                               ("key dedup / chain / table kernels + prepare_kernel + key_verify_kernel + resolve_kernel (one batch, key-table path)"
+                                if min(n_keys, n) * 16 <= n and n >= 65536 else "prepare_kernel + verify_kernel + resolve_kernel (one batch)"),
                      "kernel_ms": kernel_ms,
                      "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6; "
                              "traffic / alu_roofline are null unless profiles/pmc_latest.json was measured on this csrc hash"},
@@ -372,6 +377,8 @@ def main():
                     help="feed the reference's wire formats (compressed points, decoded on the device)")
     ap.add_argument("--ext", action="store_true",
                     help="feed extended coordinates (U, V, Z per point, normalised on the device)")
+    ap.add_argument("--keys", type=int, default=N_KEYS,
+                    help="distinct key pairs per GPU (default 4096, SURVEY.md 8d); the item count for unique keys")
     ap.add_argument("--lib", default=None, help="another in-tree build of the engine (A/B timing of kernel variants)")
     args = ap.parse_args()
 
@@ -401,8 +408,16 @@ def main():
     records, all_ok = {}, True
     for scheme in schemes:
         n = items_per_gpu(scheme, world, args.log2_items_per_gpu)
-        rec, ok = run_scheme(eng, scheme, n, args, dist, rank, world, with_cpu)
+        rec, ok = run_scheme(eng, scheme, n, args, dist, rank, world, with_cpu, args.keys)
         records[scheme] = rec
+        all_ok = all_ok and ok
+        torch.cuda.empty_cache()
+    unique = None
+    if args.scheme == "all" and not (args.wire or args.ext):
+        # the same size with every signature under its own key: no key repeats, so the engine's key tables cannot
+        # engage and every public key is a fresh variable point (the worst case for the path; round 1's number)
+        n = items_per_gpu("single", world, args.log2_items_per_gpu)
+        unique, ok = run_scheme(eng, "single", n, args, dist, rank, world, False, n_keys=n)
         all_ok = all_ok and ok
         torch.cuda.empty_cache()
 
@@ -426,7 +441,9 @@ def main():
                        "input_format": "wire (compressed points)" if args.wire else "extended (U, V, Z)" if args.ext else "affine",
                        "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
                        "distributed": {"backend": backend, "world_size": world},
-                       "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points"},
+                       "distinct_keys_per_gpu": head["distinct_keys_per_gpu"],
+                       "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points; keys as SURVEY.md 8(d): "
+                              "4 096 key pairs, item i signed by key i mod 4 096"},
             "bit_exact": head["bit_exact"],
             "roofline": head["roofline"],
             "alu_roofline": head["alu_roofline"],
@@ -435,6 +452,11 @@ def main():
             out["cpu_baseline"] = head["cpu_baseline"]
         if len(schemes) > 1:        # BASELINE.json metric: "single + double" (and configs[4], the per-item generator)
             out["schemes"] = {s: records[s] for s in schemes[1:]}
+        if unique is not None:
+            out["unique_keys"] = {k: unique[k] for k in ("value", "unit", "ms_per_step", "workload", "distinct_keys_per_gpu",
+                                                          "bit_exact", "roofline")}
+            out["unique_keys"]["note"] = ("single scheme, every signature under its own public key: the key-table path cannot "
+                                          "engage; `value` above is the SURVEY.md 8(d) workload, whose 4 096 keys repeat")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

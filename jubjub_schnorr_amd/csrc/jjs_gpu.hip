@@ -96,14 +96,24 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
     }
 }
 __global__ __launch_bounds__(BLOCK) void key_assign_kernel(key_params K) {
-    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK, first = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t base = 0; base < K.n; base += total) {           // wave-uniform trip count: ballots below
+        const uint64_t item = base + first;
         for (uint32_t c = 0; c < K.n_cols; ++c) {
             const key_column C = kt_col(K, (int32_t)c);
-            if (C.rep[item] != (uint32_t)item) continue;
-            const uint32_t id = atomicAdd(&K.counters[c], 1u);
-            C.keyid[item] = id;
-            if (id < K.max_keys) C.key_item[id] = (uint32_t)item;
+            const bool is_rep = item < K.n && C.rep[item] == (uint32_t)item;
+            // one atomic per wave (a batch of unique keys would otherwise put 2^20 atomics on one counter)
+            const unsigned long long m = __ballot(is_rep);
+            if (!m) continue;
+            uint32_t start = 0;
+            if (lane == (uint32_t)__ffsll((long long)m) - 1u) start = atomicAdd(&K.counters[c], (uint32_t)__popcll(m));
+            start = (uint32_t)__shfl((int)start, __ffsll((long long)m) - 1);
+            if (is_rep) {
+                const uint32_t id = start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                C.keyid[item] = id;
+                if (id < K.max_keys) C.key_item[id] = (uint32_t)item;
+            }
         }
     }
 }
@@ -625,7 +635,7 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     while (slots < 2 * P.n) slots <<= 1;
     auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + pad(K.max_keys) +
-                           pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4) + pad((size_t)K.max_keys * KT_POSITIONS * TABLE_WORDS * 4);
+                           pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4) + pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
     if (int rc = ensure_keys(256 + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
@@ -640,7 +650,7 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
         C.key_item = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * 4);
         C.key_flags = p; p += pad(K.max_keys);
         C.bases = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4);
-        C.tables = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * TABLE_WORDS * 4);
+        C.tables = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
     }
     return JJS_OK;
 }
@@ -736,7 +746,11 @@ int init_device(device_state& d, int ordinal) {
     HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&d.key_stream, hipStreamNonBlocking));
+    {   // the per-key kernels are few, long waves that must finish before the challenge hashes do: dispatch them first
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&d.key_stream, hipStreamNonBlocking, hi));
+    }
     HIP_TRY(hipEventCreateWithFlags(&d.key_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.key_join, hipEventDisableTiming));
     for (int i = 0; i < 33; ++i) {

@@ -13,10 +13,10 @@
 //                 than they save: a device flag sends the batch down the throughput path instead (both sets of
 //                 kernels are queued, the one that is not wanted leaves at once; no host synchronisation).
 //   3. per key    `is_valid` of the key point ONCE per key (src/keys/public.rs:159-164: canonical, on the curve,
-//                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(4i) * P, i = 0..63, and
-//                 the tables {0..8} * B_i (signed 4-bit digits, as recode_signed4 produces them).
+//                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(W i) * P and the tables
+//                 {0 .. 2^(W-1)} * B_i for signed W-bit digits (W = KT_WINDOW).
 //   4. per item   challenge hash as before (prepare_item in keyed mode: no half-size scalars, no combined test);
-//                 then  acc = sum_i digit_i(c) * B_i  (64 additions, no doubling) + u*G from the fixed-base comb
+//                 then  acc = sum_i digit_i(c) * B_i  (51 additions for W = 5, no doubling) + u*G from the fixed-base comb
 //                 (16 additions), compared with R projectively: the reference's own equation u*G + c*PK == R
 //                 (src/keys/public.rs:128-130), computed exactly by the complete addition law.
 //   Subgroup membership of R: if the equation holds and the key is torsion-free then R = u*G + c*PK is in the
@@ -29,7 +29,18 @@
 
 namespace jjs {
 
-constexpr int KT_POSITIONS = 64;                 // signed 4-bit digits of a scalar below 2^252
+// Signed digits of KT_WINDOW bits: a scalar below 2^252 has KT_POSITIONS of them (the top one unsigned and small),
+// a table holds the multiples 0 .. 2^(KT_WINDOW-1) of its base.  Wider windows trade per-key work and memory
+// (positions x entries) for per-signature additions: 4 -> 64 additions / 83 KB per key, 5 -> 51 / 125 KB,
+// 6 -> 43 / 204 KB.  Measured on the SURVEY.md 8(d) workload (~128 signatures per key): profiles/r02*_kt_window.
+#ifndef JJS_KT_WINDOW
+#define JJS_KT_WINDOW 5
+#endif
+constexpr int KT_WINDOW = JJS_KT_WINDOW;
+constexpr int KT_POSITIONS = (252 + KT_WINDOW) / KT_WINDOW;
+constexpr int KT_ENTRIES = (1 << (KT_WINDOW - 1)) + 1;
+constexpr int KT_TABLE_WORDS = KT_ENTRIES * ENTRY_WORDS;
+static_assert(KT_WINDOW >= 4 && KT_WINDOW <= 6, "digit extraction assumes a digit spans at most two words");
 constexpr uint32_t KT_MIN_MULTIPLICITY = 16;     // the tables pay from ~6 signatures per key; margin for their memory
 constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
@@ -43,8 +54,8 @@ struct key_column {
     uint32_t* keyid;         // [n] dense id of the item's key
     uint32_t* key_item;      // [max_keys] representative item of a key
     uint8_t* key_flags;      // [max_keys] KT_KEY_*
-    uint32_t* bases;         // [max_keys][KT_POSITIONS][36]: 2^(4i) * P in extended coordinates
-    uint32_t* tables;        // [max_keys][KT_POSITIONS][TABLE_WORDS]: {0..8} * 2^(4i) * P, cached-addend form
+    uint32_t* bases;         // [max_keys][KT_POSITIONS][36]: 2^(KT_WINDOW i) * P in extended coordinates
+    uint32_t* tables;        // [max_keys][KT_POSITIONS][KT_TABLE_WORDS]: {0 .. 2^(KT_WINDOW-1)} * base, cached-addend form
 };
 struct key_params {
     uint32_t n_cols, max_keys;
@@ -95,7 +106,7 @@ JJS_HD uint32_t* kt_base(const key_column& C, uint32_t id, uint32_t pos) {
     return C.bases + ((size_t)id * KT_POSITIONS + pos) * KT_BASE_WORDS;
 }
 JJS_HD uint32_t* kt_table(const key_column& C, uint32_t id, uint32_t pos) {
-    return C.tables + ((size_t)id * KT_POSITIONS + pos) * TABLE_WORDS;
+    return C.tables + ((size_t)id * KT_POSITIONS + pos) * KT_TABLE_WORDS;
 }
 JJS_HD void kt_store_ext(uint32_t* dst, const ext_pt& p) {
 #pragma unroll
@@ -120,19 +131,19 @@ JJS_HD void kt_chain_key(const key_column& C, uint32_t id) {
     kt_store_ext(kt_base(C, id, 0), p);
     for (uint32_t pos = 1; pos < (uint32_t)KT_POSITIONS; ++pos) {
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) p = ext_double(p, j == 3);
+        for (int j = 0; j < KT_WINDOW; ++j) p = ext_double(p, j == KT_WINDOW - 1);
         kt_store_ext(kt_base(C, id, pos), p);
     }
 }
 
-// table[j] = j * P for j = 0..8, P in extended coordinates (the cached-addend entries keep their Z)
+// table[j] = j * P for j = 0 .. KT_ENTRIES-1, P in extended coordinates (the cached-addend entries keep their Z)
 JJS_HD void kt_build_table(uint32_t* tab, const ext_pt& p1) {
     const niels_pt n1 = to_niels(p1);
     store_niels(tab, niels_identity());
     store_niels(tab + ENTRY_WORDS, n1);
     ext_pt acc = ext_double(p1, true);
     store_niels(tab + 2 * ENTRY_WORDS, to_niels(acc));
-    for (int j = 3; j <= 8; ++j) {
+    for (int j = 3; j < KT_ENTRIES; ++j) {
         acc = ext_add_niels(acc, n1, false, true);
         store_niels(tab + j * ENTRY_WORDS, to_niels(acc));
     }
@@ -141,10 +152,46 @@ JJS_HD void kt_table_lane(const key_column& C, uint32_t id, uint32_t pos) {
     kt_build_table(kt_table(C, id, pos), kt_load_ext(kt_base(C, id, pos)));
 }
 
-// acc + s * P for the key `id` of column C, s < 2^252: 64 additions, no doubling.  T of the result is valid.
+// s + sum_{i < POSITIONS-1} 2^(W-1) * 2^(W i): digit i of the sum, minus 2^(W-1), is signed digit i of s; the top
+// digit is unsigned (at most 5 for s < 2^252)
+JJS_HD constexpr uint32_t kt_recode_word(int w) {
+    uint32_t v = 0;
+    for (int i = 0; i < KT_POSITIONS - 1; ++i) {
+        const int bit = KT_WINDOW * i + KT_WINDOW - 1;
+        if ((bit >> 5) == w) v |= 1u << (bit & 31);
+    }
+    return v;
+}
+JJS_HD words8 kt_recode(const words8& s) {
+    constexpr uint32_t K[8] = {kt_recode_word(0), kt_recode_word(1), kt_recode_word(2), kt_recode_word(3),
+                               kt_recode_word(4), kt_recode_word(5), kt_recode_word(6), kt_recode_word(7)};
+    words8 r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t t = (uint64_t)s.w[i] + K[i] + carry;
+        r.w[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    return r;
+}
+// acc + (digit `pos` of the recoded scalar) * base_pos; pos is wave-uniform, the digit is per lane
+JJS_HD ext_pt kt_add_digit(const ext_pt& acc, const uint32_t* tab, const words8& sc, int pos) {
+    const int bit = KT_WINDOW * pos, wi = bit >> 5, sh = bit & 31;
+    uint32_t v = word_at(sc, wi) >> sh;
+    if (sh + KT_WINDOW > 32) v |= word_at(sc, wi + 1 > 7 ? 7 : wi + 1) << (32 - sh);
+    const uint32_t raw = v & ((1u << KT_WINDOW) - 1u);
+    const bool top = pos == KT_POSITIONS - 1;
+    const int d = top ? (int)(word_at(sc, wi) >> sh) : (int)raw - (1 << (KT_WINDOW - 1));
+    const bool neg = d < 0;
+    uint32_t idx = (uint32_t)(neg ? -d : d);
+    idx = idx >= (uint32_t)KT_ENTRIES ? (uint32_t)KT_ENTRIES - 1u : idx;     // out-of-range (malformed) scalars only
+    return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg, true);
+}
+// acc + s * P for the key `id` of column C, s < 2^252: KT_POSITIONS additions, no doubling.  T of the result is valid.
 JJS_HD ext_pt kt_add_scalar(ext_pt acc, const key_column& C, uint32_t id, const words8& s) {
-    const words8 sc = recode_signed4(s);
-    for (int pos = KT_POSITIONS - 1; pos >= 0; --pos) acc = add_window(acc, kt_table(C, id, (uint32_t)pos), sc, pos, true, 63, false);
+    const words8 sc = kt_recode(s);
+    for (int pos = KT_POSITIONS - 1; pos >= 0; --pos) acc = kt_add_digit(acc, kt_table(C, id, (uint32_t)pos), sc, pos);
     return acc;
 }
 

@@ -119,7 +119,7 @@ static void run_keyed(verify_params P) {
         }
         const size_t nk = key_item[c].size();
         counters[c] = (uint32_t)nk;
-        flags[c].resize(nk + 1); bases[c].resize(nk * KT_POSITIONS * KT_BASE_WORDS + 4); tables[c].resize(nk * KT_POSITIONS * TABLE_WORDS + 8);
+        flags[c].resize(nk + 1); bases[c].resize(nk * KT_POSITIONS * KT_BASE_WORDS + 4); tables[c].resize(nk * KT_POSITIONS * KT_TABLE_WORDS + 8);
         C.keyid = keyid[c].data(); C.key_item = key_item[c].data(); C.key_flags = flags[c].data();
         C.bases = bases[c].data();
         C.tables = (uint32_t*)(((uintptr_t)tables[c].data() + 15) & ~(uintptr_t)15);
