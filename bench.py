@@ -326,7 +326,9 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     algo_bytes = WIRE_BYTES[scheme] if args.wire else (EXT_BYTES[scheme] if args.ext else ALGO_BYTES[scheme])
     achieved = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
     traffic, alu = None, None
-    pmc = None if (args.wire or args.ext or n_keys != N_KEYS) else committed_pmc(scheme, n)
+    pmc = None
+    if not (args.wire or args.ext) and (n_keys == N_KEYS or n_keys >= n):
+        pmc = committed_pmc(scheme + ("_unique_keys" if n_keys >= n else ""), n)
     if pmc:
         traffic = pmc.get("hbm_bytes_per_launch")
         # the binding roofline: VALU issue.  Instruction count per launch from the committed PMC pass

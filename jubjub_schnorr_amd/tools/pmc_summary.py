@@ -6,7 +6,8 @@
 <trace_dir>: output of  rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
 <pmc_dir>s : outputs of rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py ...   (one pass per
              counter group, as MI355X_MICROARCH.md prescribes)
-One batch = prepare_kernel, verify_kernel and resolve_kernel, one launch each; counters are summed over the three
+One batch = one launch of each kernel in KERNELS (throughput path: prepare, verify, resolve; key-table path: the
+key_* kernels, prepare, key_verify, resolve, and a verify_kernel that leaves at once); counters are summed over them
 and averaged over the batches of the run.  HBM bytes = FETCH_SIZE (KB) x 2 (gfx950 correction for 16 B/lane
 loads) + WRITE_SIZE (KB).
 """
@@ -16,7 +17,10 @@ import json
 import os
 import sys
 
-KERNELS = ("prepare_kernel", "verify_kernel", "resolve_kernel")
+# every kernel one batch launches (the key-table path adds the key_* kernels; verify_kernel then leaves at once)
+KERNELS = ("prepare_kernel", "verify_kernel", "resolve_kernel", "key_dedup_kernel", "key_assign_kernel", "key_spread_kernel",
+           "key_chain_kernel", "key_table_kernel", "key_verify_kernel")
+DOMINANT = ("key_verify_kernel", "verify_kernel")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -36,8 +40,8 @@ def read_counters(d):
             if not k:
                 continue
             out.setdefault(row["Counter_Name"], {}).setdefault(k, []).append(float(row["Counter_Value"]))
-            if k == "verify_kernel":
-                meta = {"grid_size": int(row["Grid_Size"]), "lds_block_size": int(row["LDS_Block_Size"]),
+            if k in DOMINANT and float(row["Counter_Value"]) > 0 and (k == "key_verify_kernel" or "dominant_kernel" not in meta):
+                meta = {"dominant_kernel": k, "grid_size": int(row["Grid_Size"]), "lds_block_size": int(row["LDS_Block_Size"]),
                         "scratch_size": int(row["Scratch_Size"]), "vgpr_count": int(row["VGPR_Count"]),
                         "sgpr_count": int(row["SGPR_Count"])}
     return out, meta
@@ -60,6 +64,7 @@ ALGO_BYTES = {"single": 196, "double": 324, "vargen": 260}
 def main():
     tag, variant, trace_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
     scheme = os.environ.get("JJS_PMC_SCHEME", "single")
+    unique = os.environ.get("JJS_PMC_UNIQUE_KEYS") == "1"       # the passes ran bench.py --keys <items>: throughput path
     sys.path.insert(0, ROOT)
     import bench
     stats = read_stats(trace_dir)
@@ -85,8 +90,11 @@ def main():
         summary["counters"][name] = entry
     summary.update(meta)
     summary["kernel_ms_rocprof"] = stats
+    # key_chain / key_table run on a second stream beside prepare_kernel: the sum of the kernel times is an upper
+    # bound of the batch time (bench.py's HIP-event time is the batch time)
     batch_ms = sum(v["avg_ms"] for v in stats.values())
     summary["batch_ms_rocprof"] = batch_ms
+    summary["batch_ms_rocprof_note"] = "sum over kernels; key_chain_kernel and key_table_kernel overlap prepare_kernel"
     if "FETCH_SIZE" in per_batch and "WRITE_SIZE" in per_batch:
         summary["hbm_bytes_per_launch"] = (2.0 * per_batch["FETCH_SIZE"] + per_batch["WRITE_SIZE"]) * 1024.0
         summary["hbm_bytes_note"] = ("FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md HBM section (16 B/lane loads; "
@@ -100,7 +108,8 @@ def main():
             cycles = per_batch["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
             summary["effective_clock_ghz"] = cycles / (batch_ms * 1e-3) / 1e9
             summary["cycles_per_valu_instr_per_simd"] = cycles * 1024 / valu
-    suffix = "" if scheme == "single" else "_" + scheme
+    suffix = ("" if scheme == "single" else "_" + scheme) + ("_unique_keys" if unique else "")
+    summary["keys"] = "every signature under its own key (throughput path)" if unique else "4096 key pairs (SURVEY.md 8d; key-table path)"
     out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary{suffix}.json")
     json.dump(summary, open(out, "w"), indent=1)
     # profiles/pmc_latest.json: what bench.py may quote -- only for the code it was measured on (csrc hash)
@@ -111,7 +120,7 @@ def main():
         latest = {}
     if latest.get("csrc_sha256") != summary["csrc_sha256"]:
         latest = {"csrc_sha256": summary["csrc_sha256"], "schemes": {}}
-    latest["schemes"][scheme] = {"items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
+    latest["schemes"][scheme + ("_unique_keys" if unique else "")] = {"items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
                                  "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
                                  "source": f"profiles/{tag}_pmc_summary{suffix}.json"}
     json.dump(latest, open(latest_path, "w"), indent=1)
