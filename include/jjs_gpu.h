@@ -134,7 +134,7 @@ int jjs_compress_dev(const void* affine, size_t n, void* out, void* stream);
  * 114-118, src/signatures.rs:62-65) and normalises them itself with one field inversion per point
  * (`to_hash_inputs()`, src/signatures.rs:127-128).  These entry points take every point as 96 bytes =
  * U || V || Z (three canonical field elements; the affine point is (U/Z, V/Z); `get_u()/get_v()/get_z()` of the
- * Rust type through `BlsScalar::to_bytes`) and normalise on the device with one inversion shared by many items,
+ * Rust type -- reference tests/keys.rs:48-50 -- through `BlsScalar::to_bytes`) and normalise on the device with one inversion shared by many items,
  * so a shim does no field arithmetic at all.  Scalars and m as everywhere else.  Same statuses; additionally a
  * coordinate >= q gives 3 and Z = 0 (not a curve point in any representation) gives 1.  Argument order as the
  * affine entry points. */

@@ -17,8 +17,9 @@ extern "C" {
  * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars), bit4 = every window / comb
  * lookup of every lane reads one shared, cached table entry (what the gathers cost); 0 restores the full path. */
 int jjs_debug_skip_phases(unsigned mask);
-/* Path selection for A/B timing (results stay exact): 0 = by batch size (product behaviour), 1 = always the
- * throughput path, 2 = the latency path for every single / double call of at most 16 384 items; 0x42 / 0x82 = the
+/* Path selection for A/B timing (results stay exact): 0 = by batch size and key repetition (product behaviour),
+ * 1 = never the latency path, 3 = never the latency path and never the key tables (every key a fresh variable
+ * point), 2 = the latency path for every single / double call of at most 16 384 items; 0x42 / 0x82 = the
  * latency path with the scalars cut into 4 / 8 pieces whatever the size. */
 int jjs_debug_force_path(int which);
 /* Test mode for boxes with one GPU: a later jjs_init(k) with k above the visible device count creates k logical

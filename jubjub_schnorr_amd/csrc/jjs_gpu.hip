@@ -660,7 +660,7 @@ bool small_path_applies(const verify_params& P) {
     for (uint32_t k = 0; k < P.n_eq; ++k)
         if (!P.eq[k].comb) return false;               // fixed-generator equations only (single, double)
 #if defined(JJS_PROFILING)
-    if (g_force_path == 1) return false;
+    if (g_force_path == 1 || g_force_path == 3) return false;
     if (g_force_path == 2) return P.n <= SMALL_SLOT_ITEMS;
 #endif
     return P.n <= SMALL_PATH_MAX_ITEMS[P.n_eq];
@@ -1686,7 +1686,7 @@ int jjs_debug_skip_phases(unsigned mask) {
 }
 int jjs_debug_force_path(int which) {
     std::lock_guard<std::mutex> lock(L.mu);
-    g_force_path = which & 3;                       // 0 by size, 1 throughput, 2 latency
+    g_force_path = which & 3;                       // 0 by size and keys, 1 throughput (key tables allowed), 2 latency, 3 throughput without key tables
     g_force_positions = (which >> 4) == 4 || (which >> 4) == 8 ? (which >> 4) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
     return JJS_OK;
 }

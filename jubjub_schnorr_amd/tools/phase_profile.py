@@ -19,7 +19,7 @@ def main():
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     _ffi.select_library(_ffi.PROFILING_LIB_PATH)      # the ablation switches exist only in the -DJJS_PROFILING build
     eng = jjs.engine()
-    _ffi.check(_ffi.lib().jjs_debug_force_path(1), "force_path")      # the throughput path is what is profiled
+    _ffi.check(_ffi.lib().jjs_debug_force_path(3), "force_path")      # the throughput path, without key tables, is what is profiled
     arrays, _ = bench.make_inputs(eng, scheme, 1 << log2n, 0)
     call = [arrays[k] for k in bench.ARG_ORDER[scheme]]
 

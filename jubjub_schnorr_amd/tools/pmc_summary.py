@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 def kernel_of(name: str):
     for k in KERNELS:
-        if k + "(" in name:
+        if "::" + k + "(" in name or name.startswith(k + "("):      # "verify_kernel(" is also a suffix of key_verify_kernel(
             return k
     return None
 
@@ -104,10 +104,16 @@ def main():
         valu = per_batch["SQ_INSTS_VALU"]
         summary["valu_wave_instr_per_launch"] = valu
         summary["valu_wave_instr_per_64_verifies"] = valu / ((1 << 20) / 64)
-        if "GRBM_GUI_ACTIVE" in per_batch and batch_ms:
+        overlapped = stats.get("key_verify_kernel", {}).get("avg_ms", 0.0) > 0.05      # key-table path: kernels on two streams
+        if "GRBM_GUI_ACTIVE" in per_batch and batch_ms and not overlapped:
             cycles = per_batch["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
             summary["effective_clock_ghz"] = cycles / (batch_ms * 1e-3) / 1e9
             summary["cycles_per_valu_instr_per_simd"] = cycles * 1024 / valu
+        elif overlapped:
+            summary["effective_clock_ghz"] = None
+            summary["effective_clock_note"] = ("not derived: key_chain / key_table overlap prepare_kernel, so neither the sum of "
+                                               "kernel times nor the sum of per-dispatch busy cycles is the batch's; see the "
+                                               "unique-keys summary (sequential kernels) and clock_power_*.jsonl")
     suffix = ("" if scheme == "single" else "_" + scheme) + ("_unique_keys" if unique else "")
     summary["keys"] = "every signature under its own key (throughput path)" if unique else "4096 key pairs (SURVEY.md 8d; key-table path)"
     out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary{suffix}.json")

@@ -4,13 +4,12 @@
 # Usage (through gpurun): bash scripts/clock_sample.sh <tag>   -> gpurun_out/clock_power_<tag>.jsonl
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r02}; OUT=$R/gpurun_out/clock_power_${T}.jsonl; : > $OUT
 cd $R
-timeout -k 10 120 python bench.py --scheme single --no-cpu-baseline --steps 400 --warmup 5 > gpurun_out/clock_power_${T}_bench.json 2>/dev/null &
+timeout -k 10 200 python bench.py --scheme single --no-cpu-baseline --steps 2500 --warmup 5 > gpurun_out/clock_power_${T}_bench.json 2>/dev/null &
 BP=$!
-sleep 6          # import torch, build inputs
-for i in $(seq 1 10); do
+for i in $(seq 1 150); do        # one sample a second for as long as the bench process lives (import, inputs, ~26 s of batches)
   if ! kill -0 $BP 2>/dev/null; then break; fi
-  S=$(rocm-smi --showclocks --showpower --showtemp --json 2>/dev/null | tr -d '\n')
-  echo "{\"t\": $i, \"rocm_smi\": ${S:-null}}" >> $OUT
+  S=$(rocm-smi --showclocks --showpower --showuse --json 2>/dev/null | tr -d '\n')
+  if [ -n "$S" ]; then echo "{\"t\": $i, \"rocm_smi\": $S}" >> $OUT; fi
   sleep 1
 done
 wait $BP
