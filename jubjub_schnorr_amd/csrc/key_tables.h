@@ -208,7 +208,9 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
             const uint32_t id = C.keyid[item], f = C.key_flags[id];
             keys_valid = keys_valid && (f & KT_KEY_VALID) != 0;
             keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
-            acc = kt_add_scalar(acc, C, id, r.c);                             // c * PK
+            // JJS_SKIP bit 4 (profiling build only, constant false in the product): the lanes share 64 keys' tables
+            // (8 MB, cache-resident, no hot spot) -- what the gathers cost
+            acc = kt_add_scalar(acc, C, JJS_SKIP(P, 16u) ? (id & 63u) : id, r.c);     // c * PK
         }
         if (E.comb) {
             acc = add_comb(acc, E.comb, u);                                   // + u * G (G')

@@ -584,8 +584,8 @@ JJS_HD ext_pt add_comb_range(ext_pt acc, const uint32_t* comb, const words8& k, 
     for (int i = lo; i < hi; ++i) {
         constexpr int per_word = 32 / COMB_BITS;
         uint32_t digit = (word_at(k, i / per_word) >> ((i % per_word) * COMB_BITS)) & (uint32_t)(COMB_ENTRIES - 1);
-        digit = one_entry ? 1u : digit;             // profiling ablation only: one cached row entry for every lane
-        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)(one_entry ? 0 : i) * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
+        digit = one_entry ? (digit & 255u) : digit;  // profiling ablation only: 256 entries per row, cache-resident
+        const u32x4* p = reinterpret_cast<const u32x4*>(comb + ((size_t)i * COMB_ENTRIES + digit) * COMB_ENTRY_WORDS);
         uint32_t w[COMB_ENTRY_WORDS];
 #pragma unroll
         for (int k4 = 0; k4 < COMB_ENTRY_WORDS / 4; ++k4) { u32x4 v = p[k4]; w[4 * k4] = v.x; w[4 * k4 + 1] = v.y; w[4 * k4 + 2] = v.z; w[4 * k4 + 3] = v.w; }
@@ -654,9 +654,10 @@ JJS_HD words8 half_scalar_times_u(const half_scalars& h, const words8& u) {
 // Both cases run the same window loop (one copy of the doubling and addition code in the kernel).
 JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const words8& u, const words8& c,
                            const half_scalars& h, const uint32_t* shared_tab = nullptr) {
-    // shared_tab: profiling ablation only (JJS_SKIP bit 4; nullptr in the product): every window / comb lookup of
-    // every lane reads entry 1 of this one table, i.e. always hits the cache -- what the lookups cost beyond that
-    // is the price of the gathers (results are then meaningless)
+    // shared_tab: profiling ablation only (JJS_SKIP bit 4; nullptr in the product): every window lookup reads entry 1
+    // of the lane's own table and every comb lookup one of 256 entries of its row, so the working set of all lanes
+    // (19 MB + 0.5 MB) stays in L2 without any two lanes sharing an address (a single shared entry would measure a
+    // hot spot, not a cache hit) -- what the lookups cost beyond that is the price of the gathers
     const bool one_entry = shared_tab != nullptr;
     const bool fixed = (E.comb != nullptr);
 #pragma unroll 1
@@ -691,7 +692,7 @@ JJS_HD bool check_equation(const eq_desc& E, uint64_t item, uint32_t* ws, const 
         for (int t = 0; t < 2; ++t) {
             const words8 sc = select_words(t == 0, s0, s1);
             const bool need_t = (t == 0) || (fixed && win == 0);      // comb additions follow the last window
-            acc = add_window(acc, (one_entry ? shared_tab : ws) + t * TABLE_WORDS, sc, win, need_t, top, t == 1 && flip1, one_entry);
+            acc = add_window(acc, ws + t * TABLE_WORDS, sc, win, need_t, top, t == 1 && flip1, one_entry);
         }
     }
     if (fixed) {

@@ -46,10 +46,16 @@ def main():
     out["ms_challenge"] = out["ms_without_equations"] - out["ms_without_equations_and_challenge"]
     out["ms_equations"] = out["ms_without_validity"] - out["ms_without_validity_and_equations"]
     out["ms_euclid"] = out["ms_without_validity"] - out["ms_without_validity_and_euclid"]
-    # the gathers: window tables in a 340 MB workspace and comb rows in a 117 MB table, against every lookup hitting
-    # one cached entry (bit 4; point checks off in both runs so that no item goes through the resolve pass)
-    out["ms_without_validity_lookups_on_one_cached_entry"] = timed(1 | 16)
-    out["ms_gathers"] = out["ms_without_validity"] - out["ms_without_validity_lookups_on_one_cached_entry"]
+    # the gathers: window tables in a 340 MB workspace and comb rows in a 117 MB table, against lookups whose working
+    # set stays in L2 (bit 4: entry 1 of the lane's own table, 256 entries per comb row; point checks off in both runs
+    # so that no item goes through the resolve pass)
+    out["ms_without_validity_lookups_cache_resident"] = timed(1 | 16)
+    out["ms_gathers"] = out["ms_without_validity"] - out["ms_without_validity_lookups_cache_resident"]
+    # the same question for the key-table path (its tables: ~1 GB for the 8 k keys of this batch): every lane on key 0
+    _ffi.check(_ffi.lib().jjs_debug_force_path(1), "force_path")
+    out["ms_key_table_path"] = timed(0)
+    out["ms_key_table_path_lanes_on_64_keys"] = timed(16)
+    out["ms_key_table_gathers"] = out["ms_key_table_path"] - out["ms_key_table_path_lanes_on_64_keys"]
     _ffi.lib().jjs_debug_force_path(0)
     _ffi.lib().jjs_debug_skip_phases(0)
     print(json.dumps(out))
