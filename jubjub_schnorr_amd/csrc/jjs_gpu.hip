@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, 2) void small_b_kernel(small_params S) {
     acc = sb_add(acc, dpp_quad<0xB1>(acc));       // quad_perm [1,0,3,2]: partner lane ^ 1
     acc = sb_add(acc, dpp_quad<0x4E>(acc));       // quad_perm [2,3,0,1]: partner lane ^ 2
     if (pos == 8) acc = sb_add(acc, shfl_xor_ext(acc, 4));
-    bool eq_ok = ext_is_identity(acc);
+    bool eq_ok = sb_equation_holds(S, item, e, acc);
     if (S.V.n_eq == 2) eq_ok = (__shfl_xor((int)eq_ok, (int)pos) != 0) && eq_ok;
     const uint32_t st = sb_status(r.malformed, sb_points_ok(S, item), eq_ok);
     const bool writer = active && sub == 0;
@@ -430,6 +430,8 @@ constexpr size_t SMALL_SLOT_ITEMS = 16384;
 constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
 // up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
+// the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
+constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 8192, SMALL_PATH_FINE_ITEMS_VARGEN = 2048;
 
 struct device_state {
     int device = -1;               // HIP device ordinal
@@ -579,7 +581,8 @@ int ensure_small(size_t bytes) {
 
 // Latency path (small_batch.h): two launches, every signature spread over 11 (single) or 21 (double) lanes.
 int launch_small(verify_params P, hipStream_t s) {
-    uint32_t positions = P.n <= SMALL_PATH_FINE_ITEMS[P.n_eq] ? 8 : 4;
+    const bool vargen = P.eq[0].comb == nullptr;
+    uint32_t positions = P.n <= (vargen ? SMALL_PATH_FINE_ITEMS_VARGEN : SMALL_PATH_FINE_ITEMS[P.n_eq]) ? 8 : 4;
 #if defined(JJS_PROFILING)
     if (g_force_positions) positions = (uint32_t)g_force_positions;
 #endif
@@ -591,6 +594,7 @@ int launch_small(verify_params P, hipStream_t s) {
     S.tables = reinterpret_cast<uint32_t*>(sl->small);
     S.point_ok = sl->small + table_bytes;
     S.positions = positions;
+    S.windows = vargen ? 64 : 32;
     const unsigned hash_blocks = (unsigned)((P.n + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
@@ -657,13 +661,15 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
 
 bool small_path_applies(const verify_params& P) {
     if (P.n_eq < 1 || P.n_eq > 2) return false;
-    for (uint32_t k = 0; k < P.n_eq; ++k)
-        if (!P.eq[k].comb) return false;               // fixed-generator equations only (single, double)
+    const bool vargen = P.eq[0].comb == nullptr;        // single: 1 fixed-generator equation, double: 2, var-gen: 1 per-item
+    if (vargen && P.n_eq != 1) return false;
+    for (uint32_t k = 1; k < P.n_eq; ++k)
+        if (!P.eq[k].comb) return false;
 #if defined(JJS_PROFILING)
     if (g_force_path == 1 || g_force_path == 3) return false;
     if (g_force_path == 2) return P.n <= SMALL_SLOT_ITEMS;
 #endif
-    return P.n <= SMALL_PATH_MAX_ITEMS[P.n_eq];
+    return P.n <= (vargen ? SMALL_PATH_MAX_ITEMS_VARGEN : SMALL_PATH_MAX_ITEMS[P.n_eq]);
 }
 
 // Throughput path, three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy),

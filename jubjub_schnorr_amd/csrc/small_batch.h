@@ -1,4 +1,4 @@
-// Latency path for small batches (single and double scheme): one signature spread over many lanes.
+// Latency path for small batches (all three schemes): one signature spread over many lanes.
 //
 // The throughput path gives a signature one lane from start to finish, so a call costs one signature's
 // latency (~600 k dependent instructions) however few items it carries.  What the reference's callers do --
@@ -24,6 +24,9 @@
 //   reference's by the same argument; the only difference from the throughput path is that every point gets its
 //   own subgroup test, which is the reference's `is_valid` literally (src/keys/public.rs:159-164).
 //
+// The per-item-generator scheme runs the same lanes on (c over PK, u over Gen) with full-size scalars (64 windows,
+// chains up to 224 doublings: the chain, not the hash, is then the critical path) and compares the sum with R.
+//
 // ~300 k dependent instructions instead of ~600 k, for ~1.8 x the total work: used below a size threshold only.
 #pragma once
 #include "verify_core.h"
@@ -41,6 +44,7 @@ struct small_params {
     uint32_t* tables;       // [item][equation][0 = PK, 1 = R][position][TABLE_WORDS]
     uint8_t* point_ok;      // [item][4]: V.points[p] is on the curve, not the identity, torsion-free
     uint32_t positions;     // 4 or 8
+    uint32_t windows;       // signed 4-bit windows of the scalars: 32 (half-size scalars, fixed generator) or 64 (per-item generator)
 };
 
 JJS_HD uint32_t* sb_table(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
@@ -65,9 +69,10 @@ JJS_HD void build_point_table_ext(uint32_t* tab, const ext_pt& p1) {
 JJS_HD void sb_hash_item(const small_params& S, uint64_t item) {
     store_prep(S.V.prep, S.V.n, item, prepare_item(S.V, item));
 }
-// window table of 2^(128 k / positions) * P, P = PK (pt 0) or R (pt 1) of equation e
+// window table of 2^(4 k windows / positions) * P; P = PK (pt 0), or (pt 1) R for a fixed-generator equation and the
+// generator for the per-item-generator scheme
 JJS_HD void sb_chain_lane(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
-    const fe_src& src = pt == 0 ? S.V.eq[e].pk : S.V.eq[e].r;
+    const fe_src& src = pt == 0 ? S.V.eq[e].pk : (S.V.eq[e].comb ? S.V.eq[e].r : S.V.eq[e].gen);
     const fe_n pu = load_fq(src, item), pv = load_fq(src, item, 32);
     uint32_t* tab = sb_table(S, item, e, pt, k);
     if (k == 0) {                                    // wave-uniform: a launch gives every wave one position
@@ -75,7 +80,7 @@ JJS_HD void sb_chain_lane(const small_params& S, uint64_t item, uint32_t e, uint
         return;
     }
     ext_pt p = ext_from_affine(pu, pv);
-    const int n_dbl = (128 / (int)S.positions) * (int)k;
+    const int n_dbl = 4 * ((int)S.windows / (int)S.positions) * (int)k;
     for (int i = 0; i < n_dbl; ++i) p = ext_double(p, i == n_dbl - 1);
     build_point_table_ext(tab, p);
 }
@@ -89,27 +94,37 @@ JJS_HD void sb_point_lane(const small_params& S, uint64_t item, uint32_t p) {
 }
 
 // ---- phase B ------------------------------------------------------------------------------------------
-// lane k of equation e: its 32 / positions signed windows of (a over PK_k, -b over R_k) and its 16 / positions comb
-// digits of (b*u)*G
+// lane k of equation e: its windows / positions signed windows of both scalars over the tables at position k and, for a
+// fixed generator, its 16 / positions comb digits of (b*u)*G.
+//   fixed generator:    a over table(PK_k), -b over table(R_k)        (sum must be the identity)
+//   per-item generator: c over table(PK_k),  u over table(Gen_k)      (sum must equal R)
 JJS_HD ext_pt sb_piece(const small_params& S, uint64_t item, uint32_t e, uint32_t k, const prep_record& r) {
+    const bool fixed = S.V.eq[e].comb != nullptr;
     const words8 u = load_words(S.V.u, item);
-    const words8 w = half_scalar_times_u(r.h, u);
-    const words8 s0 = recode_signed4_128(r.h.a), s1 = recode_signed4_128(r.h.b);
+    const words8 s0 = fixed ? recode_signed4_128(r.h.a) : recode_signed4(r.c);
+    const words8 s1 = fixed ? recode_signed4_128(r.h.b) : recode_signed4(u);
     const uint32_t* t0 = sb_table(S, item, e, 0, k);
     const uint32_t* t1 = sb_table(S, item, e, 1, k);
-    const bool flip1 = !r.h.b_neg;                                   // table 1 contributes -b*R
-    const int windows = 32 / (int)S.positions, comb_digits = COMB_WINDOWS / (int)S.positions;
+    const bool flip1 = fixed && !r.h.b_neg;                          // table 1 contributes -b*R
+    const int windows = (int)S.windows / (int)S.positions, top = (int)S.windows - 1;
     ext_pt acc = ext_identity();
     for (int win = windows - 1; win >= 0; --win) {
         if (win != windows - 1) {
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) acc = ext_double(acc, j == 3);
         }
-        const int nib = windows * (int)k + win;                      // digit 31 is the unsigned top digit
-        acc = add_window(acc, t0, s0, nib, true, 31, false);
-        acc = add_window(acc, t1, s1, nib, win == 0, 31, flip1);     // doublings follow, except before the comb digits
+        const int nib = windows * (int)k + win;                      // digit `top` is the unsigned top digit
+        acc = add_window(acc, t0, s0, nib, true, top, false);
+        acc = add_window(acc, t1, s1, nib, !fixed || win == 0, top, flip1);   // T: for the comb digits / the lane sums
     }
-    return add_comb_range(acc, S.V.eq[e].comb, w, comb_digits * (int)k, comb_digits * (int)k + comb_digits, true);
+    if (!fixed) return acc;
+    const int comb_digits = COMB_WINDOWS / (int)S.positions;
+    return add_comb_range(acc, S.V.eq[e].comb, half_scalar_times_u(r.h, u), comb_digits * (int)k, comb_digits * (int)k + comb_digits, true);
+}
+// the verdict of an equation from the sum of its pieces
+JJS_HD bool sb_equation_holds(const small_params& S, uint64_t item, uint32_t e, const ext_pt& total) {
+    if (S.V.eq[e].comb) return ext_is_identity(total);
+    return ext_eq_affine(total, load_fq(S.V.eq[e].r, item), load_fq(S.V.eq[e].r, item, 32));
 }
 JJS_HD ext_pt sb_add(const ext_pt& a, const ext_pt& b) { return ext_add_niels(a, to_niels(b), false, true); }
 
@@ -138,7 +153,7 @@ JJS_HD uint32_t sb_verify_item_serial(const small_params& S, uint64_t item) {
         for (uint32_t step = 1; step < S.positions; step <<= 1)          // the device's shuffle tree: lane ^ 1, ^ 2, ^ 4
             for (uint32_t k = 0; k < S.positions; k += 2 * step) part[k] = sb_add(part[k], part[k + step]);
         const ext_pt total = part[0];
-        eq_ok = ext_is_identity(total) && eq_ok;
+        eq_ok = sb_equation_holds(S, item, e, total) && eq_ok;
     }
     return sb_status(r.malformed, sb_points_ok(S, item), eq_ok);
 }

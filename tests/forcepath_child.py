@@ -21,7 +21,7 @@ def main() -> None:
     eng = jjs.engine()
     lib = _ffi.lib()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    for scheme in ("single", "double"):
+    for scheme in ("single", "double", "vargen"):
         cases = [make_batch(scheme, n, seed=700 + n, n_keys=16) for n in (1, 3, 63, 65, 257, 1000, 5000)]
         cases += [edge_cases(scheme), torsion_grid(scheme, reps=2, extra=0 if scheme == "single" else 100)]
         for b in cases:

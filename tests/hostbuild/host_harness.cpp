@@ -80,6 +80,7 @@ static void run_small(verify_params P, uint32_t positions) {
     std::vector<uint32_t> tables(sb_table_words_per_item(P.n_eq, positions) * P.n + 4);
     small_params S{};
     S.positions = positions;
+    S.windows = P.eq[0].comb ? 32 : 64;
     P.small_mode = 1;
     P.prep = (uint8_t*)(((uintptr_t)prep.data() + 15) & ~(uintptr_t)15);
     S.V = P;
@@ -179,6 +180,14 @@ int jjs_host_verify_small_double(const uint8_t* u, const uint8_t* R, const uint8
     unsigned long long t[4] = {0, 0, 0, 0};
     run_small(params_double(u, R, Rp, PK, PKp, m, n, (const uint8_t*)g_tag, g_comb_g.data(), g_comb_gn.data(),
                             out_ptrs{status, t, nullptr, nullptr}), (uint32_t)positions);
+    if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
+    return 0;
+}
+
+int jjs_host_verify_small_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                                 size_t n, uint8_t* status, uint64_t* tally, int positions) {
+    unsigned long long t[4] = {0, 0, 0, 0};
+    run_small(params_vargen(u, R, PK, Gen, m, n, out_ptrs{status, t, nullptr, nullptr}), (uint32_t)positions);
     if (tally) for (int i = 0; i < 4; ++i) tally[i] = t[i];
     return 0;
 }
