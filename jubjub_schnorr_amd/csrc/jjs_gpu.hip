@@ -431,7 +431,7 @@ constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
 // up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
-constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 8192, SMALL_PATH_FINE_ITEMS_VARGEN = 2048;
+constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
 struct device_state {
     int device = -1;               // HIP device ordinal

@@ -540,7 +540,8 @@ def test_both_paths_at_every_size():
     assert p.returncode == 0 and "FORCEPATH OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 16384), ("single", 4096), ("double", 4096)])
+@pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 16384), ("vargen", 16384), ("single", 4096), ("double", 4096),
+                                          ("vargen", 4096)])
 def test_path_boundary(eng, scheme, limit):
     """Either side of the sizes at which the product changes method (csrc/jjs_gpu.hip SMALL_PATH_FINE_ITEMS: 8 -> 4
     pieces on the latency path; SMALL_PATH_MAX_ITEMS: latency -> throughput path), against the oracle."""
