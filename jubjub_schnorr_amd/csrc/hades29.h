@@ -46,11 +46,37 @@ JJS_HD void hades_matrix(hades_state& o, const fe_n (&t)[5]) {
 // been pushed forward so that only lane 4 receives one.  After round 68 the state is multiplied by
 // lambda_end.  Same function of the state as the textbook round sequence (checked in the generator, on
 // the host build and on the GPU).
-JJS_HD void hades_permute(hades_state& st) {
+//
+// coop >= 0 (device only; the latency path, small_batch.h): eight adjacent lanes hold the same state and work on the
+// same permutation; in a full round lane j computes the S-box of state element min(j, 4) only and the five results
+// are exchanged (45 ds_bpermute), so a full round costs one S-box instead of five on the critical path.  The linear
+// layer and the partial rounds run redundantly on every lane.  Same arithmetic on the same values: same result.
+JJS_HD void hades_permute(hades_state& st, int coop = -1) {
     for (int r = 0; r < 68; ++r) {
         fe_n t[5];
         if (r < 4 || r >= 64) {
             const int fr = r < 4 ? r : r - 60;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (coop >= 0) {
+                const int j = coop < 4 ? coop : 4;
+                fe_n x = st.s[4];
+                fe_c rc = fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][4]);
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                    x = fq_select(j == i, st.s[i], x);
+                    rc = fq_select(j == i, fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i]), rc);
+                }
+                const fe_n mine = sbox5(fq_add(x, rc));
+                const int base = (int)(__lane_id() & ~7u);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                    for (int w = 0; w < 9; ++w) t[i].l[w] = (uint32_t)__shfl((int)mine.l[w], base + i);
+                }
+                hades_matrix(st, t);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < 5; ++i) t[i] = sbox5(fq_add(st.s[i], fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i])));
         } else {
@@ -69,7 +95,7 @@ JJS_HD void hades_permute(hades_state& st) {
 // transcript element e) and squeezes one element.  The sponge is processed in rate-4 blocks so that
 // the permutation has a single call site and no input has to stay live across a permutation.
 template <typename Fetch>
-JJS_HD fe_n poseidon_digest_tagged(int n_inputs, const fe_n& tag, Fetch fetch) {
+JJS_HD fe_n poseidon_digest_tagged(int n_inputs, const fe_n& tag, Fetch fetch, int coop = -1) {
     hades_state st;
     st.s[0] = tag;
 #pragma unroll
@@ -81,15 +107,15 @@ JJS_HD fe_n poseidon_digest_tagged(int n_inputs, const fe_n& tag, Fetch fetch) {
             int e = 4 * blk + k;
             if (e < n_inputs) st.s[1 + k] = fq_reduce(fq_norm(fq_add(st.s[1 + k], fetch(e))));
         }
-        hades_permute(st);
+        hades_permute(st, coop);
     }
     return st.s[1];
 }
 
 // transcripts of up to JJS_MAX_HASH_INPUTS elements: the SAFE tag comes from the constant table
 template <typename Fetch>
-JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch) {
-    return poseidon_digest_tagged(n_inputs, fq_as<1, 2>(fe_from_const<1, 1>(JJS_SPONGE_TAG[n_inputs])), fetch);
+JJS_HD fe_n poseidon_digest(int n_inputs, Fetch fetch, int coop = -1) {
+    return poseidon_digest_tagged(n_inputs, fq_as<1, 2>(fe_from_const<1, 1>(JJS_SPONGE_TAG[n_inputs])), fetch, coop);
 }
 
 // digest -> canonical words, low 250 bits (JubJubScalar)

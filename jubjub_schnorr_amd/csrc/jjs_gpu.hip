@@ -192,8 +192,14 @@ __global__ __launch_bounds__(BLOCK, 2) void small_a_kernel(small_params S, uint3
     const uint64_t n = S.V.n;
     if (b < hash_blocks) {
         __builtin_amdgcn_s_setprio(3);            // the critical path: ahead of co-resident chain / point waves
-        const uint64_t item = (uint64_t)b * BLOCK + threadIdx.x;
-        if (item < n) sb_hash_item(S, item);
+        const uint64_t idx = (uint64_t)b * BLOCK + threadIdx.x;
+        if (S.hash_lanes == 1) {
+            if (idx < n) sb_hash_item(S, idx);
+            return;
+        }
+        const uint64_t item = idx / SB_HASH_LANES;
+        const bool active = item < n;             // whole groups of eight lanes: the shuffles of a group stay inside it
+        sb_hash_item_coop(S, active ? item : n - 1, (int)(idx % SB_HASH_LANES), active);
         return;
     }
     const uint32_t cb = b - hash_blocks;
@@ -595,7 +601,9 @@ int launch_small(verify_params P, hipStream_t s) {
     S.point_ok = sl->small + table_bytes;
     S.positions = positions;
     S.windows = vargen ? 64 : 32;
-    const unsigned hash_blocks = (unsigned)((P.n + BLOCK - 1) / BLOCK);
+    // eight lanes per hash where the hash is the critical path (fixed generator) and the batch leaves lanes idle
+    S.hash_lanes = (!vargen && P.n <= SMALL_PATH_FINE_ITEMS[P.n_eq]) ? SB_HASH_LANES : 1;
+    const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + positions * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,

@@ -8,7 +8,8 @@
 // and everything that does not depend on the challenge runs beside the hash on other lanes:
 //
 //   phase A, three roles in one launch (role = block range):
-//     hash     1 lane / item          encodings, Poseidon challenge, truncated Euclid (a, b)        [prepare_item]
+//     hash     8 lanes / item         encodings, Poseidon challenge (the five S-boxes of a full round on five
+//                                     lanes), truncated Euclid (a, b)                                [prepare_item]
 //     chain    8 lanes / equation     P_k = 2^(32k) * P for P in {PK, R}, k = 0..3, and the window table
 //                                     {0..8} * P_k of each (the loop of phase B then needs no doubling chain
 //                                     longer than 28); 16 lanes and 16-bit pieces for the smallest batches
@@ -45,6 +46,8 @@ struct small_params {
     uint8_t* point_ok;      // [item][4]: V.points[p] is on the curve, not the identity, torsion-free
     uint32_t positions;     // 4 or 8
     uint32_t windows;       // signed 4-bit windows of the scalars: 32 (half-size scalars, fixed generator) or 64 (per-item generator)
+    uint32_t hash_lanes;    // 1, or SB_HASH_LANES: eight lanes share an item's challenge hash (smallest batches, where the
+                            // hash is the critical path and the chip has lanes to spare)
 };
 
 JJS_HD uint32_t* sb_table(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
@@ -66,8 +69,14 @@ JJS_HD void build_point_table_ext(uint32_t* tab, const ext_pt& p1) {
 }
 
 // ---- phase A ------------------------------------------------------------------------------------------
+constexpr int SB_HASH_LANES = 8;      // lanes that share one item's challenge hash on the device (hades_permute, coop)
 JJS_HD void sb_hash_item(const small_params& S, uint64_t item) {
     store_prep(S.V.prep, S.V.n, item, prepare_item(S.V, item));
+}
+// the same on eight adjacent lanes (lane j of the group); every lane ends with the same record, lane 0 stores it
+JJS_HD void sb_hash_item_coop(const small_params& S, uint64_t item, int j, bool active) {
+    const prep_record r = prepare_item(S.V, item, j == 0 && active, j);
+    if (j == 0 && active) store_prep(S.V.prep, S.V.n, item, r);
 }
 // window table of 2^(4 k windows / positions) * P; P = PK (pt 0), or (pt 1) R for a fixed-generator equation and the
 // generator for the per-item-generator scheme

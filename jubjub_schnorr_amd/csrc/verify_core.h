@@ -743,7 +743,8 @@ struct prep_record {
 // Does this batch run the key-table path?  Decided on the device after the keys have been counted.
 JJS_HD bool keyed_mode(const verify_params& P) { return P.key_flag != nullptr && *P.key_flag != 0u; }
 
-JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true) {
+// coop: see hades_permute (the latency path's hash lanes work in groups of eight); -1 everywhere else
+JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true, int coop = -1) {
     prep_record r;
     const bool keyed = keyed_mode(P);
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
@@ -768,7 +769,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     // 3. challenge
     words8 c = u;
     if (!JJS_SKIP(P, 2u)) {
-        fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); });
+        fe_n digest = poseidon_digest((int)P.n_hash, [&](int e) { return load_fq(P.hash_in[e], item); }, coop);
         c = truncate250(digest);
     }
     if (P.c_out && write_c) store_words(P.c_out, item, c);
