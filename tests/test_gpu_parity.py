@@ -530,6 +530,35 @@ def test_key_table_path_against_oracle(eng, scheme):
     assert (host(st2) == want[sel]).all()
 
 
+@pytest.mark.parametrize("n_keys", [1, 2, 8191, 8192, 8193, 1 << 17])
+def test_key_table_decision_boundary(eng, n_keys):
+    """2^17 + 5 single signatures under 1 ... 2^17 keys: either side of the engine's on-device decision (at most
+    n / 16 distinct keys -> key tables, else the throughput path), one key for every item (every lane on one hash
+    slot), statuses by construction plus an oracle sample."""
+    import torch
+    n = (1 << 17) + 5
+    gen = torch.Generator(device="cpu").manual_seed(4000 + n_keys)
+    def scal(rows, top):
+        t = torch.randint(0, 256, (rows, 32), dtype=torch.uint8, generator=gen)
+        t[:, 31] &= top
+        return t
+    key_sk = scal(n_keys, 0x07); key_sk[:, 0] |= 1
+    sk = key_sk[torch.arange(n) % n_keys].cuda()
+    rnd, m = scal(n, 0x07).cuda(), scal(n, 0x3F).cuda()
+    u, R, PK = eng.sign("single", sk, rnd, m)
+    idx = torch.arange(n, device="cuda")
+    expect = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    bad = (idx % 11) == 3
+    m = m.clone(); m[bad, 0] ^= 1
+    expect[bad] = 2
+    st, tally = eng.verify("single", u, R, PK, m)
+    assert torch.equal(st, expect)
+    assert host(tally).tolist() == [int((expect == k).sum()) for k in range(4)]
+    sel = torch.from_numpy(np.random.default_rng(n_keys).choice(n, 512, replace=False)).cuda()
+    sample = {"u": host(u[sel]), "R": host(R[sel]), "PK": host(PK[sel]), "m": host(m[sel])}
+    assert host(st[sel]).tolist() == oracle_verify("single", sample).tolist()
+
+
 def test_both_paths_at_every_size():
     """Throughput path and latency path forced in turn (profiling build, child process) on ragged sizes, edge
     cases and the torsion grid."""
