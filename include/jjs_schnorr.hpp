@@ -8,7 +8,8 @@
 //   Error                    src/error.rs:13-26
 //   to_bytes / from_bytes    src/signatures.rs:101-119, src/keys/public.rs:80-94 (wire entry points)
 // plus the batch entry points a GPU-backed crate would add (`verify_batch`, `verify_batch_bytes`).
-// Points are held as affine canonical bytes (u || v): what `to_hash_inputs()` yields.
+// Points are held as affine canonical bytes (u || v): what `to_hash_inputs()` yields; `verify_batch_extended` takes
+// them as the Rust `JubJubExtended` holds them (U || V || Z, normalised on the device: no host arithmetic).
 #pragma once
 #include <array>
 #include <cstdint>
@@ -24,6 +25,7 @@ namespace jjs {
 
 using Scalar = std::array<uint8_t, 32>;     // JubJubScalar / BlsScalar: canonical little-endian
 using AffinePoint = std::array<uint8_t, 64>;  // u || v
+using ExtendedPoint = std::array<uint8_t, 96>;  // U || V || Z, affine point (U/Z, V/Z): get_u / get_v / get_z of JubJubExtended
 using BlsScalar = Scalar;
 using JubJubScalar = Scalar;
 
@@ -168,6 +170,20 @@ class PublicKey {
         int rc = jjs_verify_single(u.data(), r.data(), pk.data(), m.data(), n, status.data(), t);
         if (rc != JJS_OK) throw EngineError(rc, "jjs_verify_single");
         if (tally) std::memcpy(tally, t, sizeof(t));
+        return detail::results(status);
+    }
+    // The same with every point in extended coordinates: what `PublicKey::verify(&self, &Signature, BlsScalar)` holds
+    // (reference src/keys/public.rs:114-118); the engine normalises on the device (jjs_verify_single_ext).
+    struct ItemExtended { ExtendedPoint pk; JubJubScalar u; ExtendedPoint R; BlsScalar message; };
+    static std::vector<VerifyResult> verify_batch_extended(const std::vector<ItemExtended>& items) {
+        const size_t n = items.size();
+        detail::Soa u(n, 32), r(n, 96), pk(n, 96), m(n, 32);
+        for (size_t i = 0; i < n; ++i) {
+            u.put(i, 0, items[i].u); r.put(i, 0, items[i].R); pk.put(i, 0, items[i].pk); m.put(i, 0, items[i].message);
+        }
+        std::vector<uint8_t> status(n);
+        int rc = jjs_verify_single_ext(u.data(), r.data(), pk.data(), m.data(), n, status.data(), nullptr);
+        if (rc != JJS_OK) throw EngineError(rc, "jjs_verify_single_ext");
         return detail::results(status);
     }
     // Batch verify straight from the reference's wire formats (`Signature::to_bytes` 64 B = u || R,

@@ -1,11 +1,17 @@
 // libjjs_gpu.so: HIP kernels (gfx950) + the C ABI of include/jjs_gpu.h.
 //
-// One signature per lane.  A batch is three launches: prepare_kernel (hash, scalar lattice, pairing
-// tests; four waves per SIMD), verify_kernel (the equations; a persistent pass whose grid is what the chip
-// can hold resident -- 256 CUs x blocks/CU from the occupancy query -- each lane striding over the batch
-// and owning WS_WORDS_PER_LANE words of workspace for its window tables) and resolve_kernel (the items
-// verify_kernel could not decide).  The per-status tally is reduced with wave ballots and one atomic per
-// wave per status.  One process can drive several devices (jjs_init); all state is per device.
+// A verification call takes one of three paths, chosen from its size and from how often its keys repeat (nothing
+// else: no switch, no environment variable), all with the same statuses:
+//   throughput  (verify_core.h)   one signature per lane: prepare_kernel (hash, scalar lattice, pairing tests; four
+//               waves per SIMD), verify_kernel (the equations; a persistent pass whose grid is what the chip holds
+//               resident, each lane owning WS_WORDS_PER_LANE words of workspace for its window tables) and
+//               resolve_kernel (the items verify_kernel could not decide);
+//   key tables  (key_tables.h)    >= 65 536 items whose keys repeat >= 16 times on average: keys deduplicated on the
+//               device, validity and window tables once per key (second stream, beside the hashes), additions only
+//               per signature (key_verify_kernel); decided on the device, no host round trip;
+//   latency     (small_batch.h)   <= 16 384 items: one signature spread over 11-45 lanes in two launches.
+// The per-status tally is reduced with wave ballots and one atomic per wave per status.  One process can drive
+// several devices (jjs_init); all state is per device, per-call state lives in call slots (call_slot).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>

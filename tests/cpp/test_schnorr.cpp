@@ -62,6 +62,19 @@ int main(int argc, char** argv) {
     uint64_t want_tally[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < res.size(); ++i) { failures += expect(res[i], singles_want[i], "batch[" + std::to_string(i) + "]"); ++want_tally[singles_want[i]]; }
     for (int k = 0; k < 4; ++k) if (tally[k] != want_tally[k]) { std::printf("FAIL tally[%d]\n", k); ++failures; }
+    // extended-coordinate entry point: the same items as (u, v, 1) -- the engine divides by Z on the device
+    {
+        std::vector<jjs::PublicKey::ItemExtended> ext;
+        for (const auto& it : singles) {
+            jjs::PublicKey::ItemExtended e{};
+            std::memcpy(e.pk.data(), it.pk.data(), 64); e.pk[64] = 1;
+            std::memcpy(e.R.data(), it.sig.R.data(), 64); e.R[64] = 1;
+            e.u = it.sig.u; e.message = it.message;
+            ext.push_back(e);
+        }
+        auto eres = jjs::PublicKey::verify_batch_extended(ext);
+        for (size_t i = 0; i < eres.size(); ++i) failures += expect(eres[i], singles_want[i], "extended[" + std::to_string(i) + "]");
+    }
     // wire entry point: the reference's own serialised bytes (line "wire single <name> <status> sig pk m")
     {
         std::ifstream in2(argv[1]);
