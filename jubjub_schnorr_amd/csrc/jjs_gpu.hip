@@ -92,12 +92,19 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
         for (uint32_t c = 0; c < K.n_cols; ++c) {
             const key_column C = kt_col(K, (int32_t)c);
             uint32_t slot = (uint32_t)kt_hash(C.src, item) & C.hash_mask;
-            for (;;) {                                     // every probe either claims a slot or meets a settled one
+            uint32_t rep = (uint32_t)item;
+            bool settled = false;
+            // every probe either claims a slot or meets a settled one; the table has at least 2 n slots, so honest
+            // keys settle within a few probes.  Keys crafted to share a slot do not get to make this loop long: after
+            // KT_MAX_PROBES the batch gives up on key tables (counters[3]) and takes the throughput path.
+            for (uint32_t probe = 0; probe < KT_MAX_PROBES && !settled; ++probe) {
                 const uint32_t cur = atomicCAS(&C.hash[slot], 0u, (uint32_t)item + 1u);
-                if (cur == 0u) { C.rep[item] = (uint32_t)item; break; }
-                if (kt_same_key(C.src, item, cur - 1u)) { C.rep[item] = cur - 1u; break; }
-                slot = (slot + 1u) & C.hash_mask;          // the table has at least 2 n slots: never full
+                if (cur == 0u) settled = true;
+                else if (kt_same_key(C.src, item, cur - 1u)) { rep = cur - 1u; settled = true; }
+                else slot = (slot + 1u) & C.hash_mask;
             }
+            if (!settled) atomicOr(&K.counters[3], 1u);
+            C.rep[item] = rep;
         }
     }
 }
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void key_assign_kernel(key_params K) {
 __global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     if (blockIdx.x == 0 && threadIdx.x == 0) {              // the decision: enough signatures per key in every column
-        bool use = true;
+        bool use = K.counters[3] == 0u;                    // no probe sequence was cut short
         for (uint32_t c = 0; c < K.n_cols; ++c) use = use && (uint64_t)K.counters[c] * KT_MIN_MULTIPLICITY <= K.n;
         K.counters[2] = use ? 1u : 0u;
     }
@@ -708,11 +715,16 @@ int launch_verify(verify_params P, hipStream_t s) {
     P.pending = sl->pending + 2;
     HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
     key_params K{};
-    const bool try_keys = key_path_applies(P);
+    bool try_keys = key_path_applies(P);
+    if (try_keys && setup_keys(P, K, s) != JJS_OK) {
+        // no room for the key arena (it is sized for n / 16 keys per column): the batch simply takes the throughput
+        // path, as it would with keys that do not repeat
+        (void)hipGetLastError();
+        try_keys = false;
+    }
     if (try_keys) {
         // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
         // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
-        if (int rc = setup_keys(P, K, s)) return rc;
         const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
         hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
         hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);

@@ -11,7 +11,9 @@
 //                 hit: two keys are merged only if they are the same bytes); keys get dense ids.
 //   2. decision   if some column has more than n / KT_MIN_MULTIPLICITY distinct keys the tables would cost more
 //                 than they save: a device flag sends the batch down the throughput path instead (both sets of
-//                 kernels are queued, the one that is not wanted leaves at once; no host synchronisation).
+//                 kernels are queued, the one that is not wanted leaves at once; no host synchronisation).  The same
+//                 happens when some key needed more than KT_MAX_PROBES probes (keys crafted to collide in the hash
+//                 table must not be able to make the call slow) or when the key arena cannot be allocated.
 //   3. per key    `is_valid` of the key point ONCE per key (src/keys/public.rs:159-164: canonical, on the curve,
 //                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(W i) * P and the tables
 //                 {0 .. 2^(W-1)} * B_i for signed W-bit digits (W = KT_WINDOW).
@@ -42,6 +44,7 @@ constexpr int KT_ENTRIES = (1 << (KT_WINDOW - 1)) + 1;
 constexpr int KT_TABLE_WORDS = KT_ENTRIES * ENTRY_WORDS;
 static_assert(KT_WINDOW >= 4 && KT_WINDOW <= 6, "digit extraction assumes a digit spans at most two words");
 constexpr uint32_t KT_MIN_MULTIPLICITY = 16;     // the tables pay from ~6 signatures per key; margin for their memory
+constexpr uint32_t KT_MAX_PROBES = 128;          // hash-table probes per key before the batch gives up on key tables
 constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
 
@@ -60,7 +63,7 @@ struct key_column {
 struct key_params {
     uint32_t n_cols, max_keys;
     key_column col[2];
-    uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 1 = key-table path
+    uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 1 = key-table path; [3] a probe sequence overflowed
     uint64_t n;
 };
 

@@ -559,6 +559,59 @@ def test_key_table_decision_boundary(eng, n_keys):
     assert host(st[sel]).tolist() == oracle_verify("single", sample).tolist()
 
 
+def test_keys_crafted_to_collide_in_the_hash_table(eng):
+    """2 000 distinct public-key byte strings built to land on ONE slot of the engine's key hash table (the hash of
+    csrc/key_tables.h is public and unkeyed, so a sender can do this): the probe sequences are cut at KT_MAX_PROBES and
+    the batch takes the throughput path; the call stays fast and every status is still the oracle's."""
+    M64 = (1 << 64) - 1
+    C = 0xFF51AFD7ED558CCD
+    C_INV = pow(C, -1, 1 << 64)
+
+    def state_before_last_chunk(key56: bytes) -> int:
+        h = 0x9E3779B97F4A7C15
+        for k in range(7):
+            h ^= int.from_bytes(key56[8 * k:8 * k + 8], "little")
+            h = (h * C) & M64
+            h ^= h >> 29
+        return h
+
+    n_good, n_bad = 1 << 17, 2000
+    n = n_good + n_bad
+    slots = 1
+    while slots < 2 * n:
+        slots <<= 1
+    mask = slots - 1
+    b = make_batch("single", n, seed=31337, n_keys=512)
+    rng = np.random.default_rng(5)
+    target = 0x2A5A5 & mask
+    for i in range(n_good, n):
+        prefix = rng.bytes(56)
+        t_hi = int.from_bytes(rng.bytes(8), "little") & ~mask & M64
+        t = t_hi | (target ^ ((t_hi >> 29) & mask))
+        x = ((t * C_INV) & M64) ^ state_before_last_chunk(prefix)
+        key = prefix + x.to_bytes(8, "little")
+        # the engine's hash of these 64 bytes ends on `target`
+        h = state_before_last_chunk(prefix) ^ x
+        h = (h * C) & M64
+        h ^= h >> 29
+        assert (h & 0xFFFFFFFF) & mask == target
+        b["PK"][i] = np.frombuffer(key, np.uint8)
+    want = oracle_verify("single", b)
+    import time
+    import torch
+    args = [dev(b[k]) for k in ARG_ORDER["single"]]
+    eng.verify("single", *args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, tally = eng.verify("single", *args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert (host(st) == want).all()
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    assert dt < 0.05, dt          # ~3 ms on the throughput path; an unbounded chain of 2 000 keys would not matter yet,
+    #                               a chain of 10^6 would: the bound is what keeps the worst case at this cost
+
+
 def test_both_paths_at_every_size():
     """Throughput path and latency path forced in turn (profiling build, child process) on ragged sizes, edge
     cases and the torsion grid."""
