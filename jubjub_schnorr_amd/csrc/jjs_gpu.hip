@@ -98,7 +98,10 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
             // keys settle within a few probes.  Keys crafted to share a slot do not get to make this loop long: after
             // KT_MAX_PROBES the batch gives up on key tables (counters[3]) and takes the throughput path.
             for (uint32_t probe = 0; probe < KT_MAX_PROBES && !settled; ++probe) {
-                const uint32_t cur = atomicCAS(&C.hash[slot], 0u, (uint32_t)item + 1u);
+                // look before claiming: with few distinct keys nearly every lane finds its slot taken, and a million
+                // compare-and-swaps on one address would queue up behind each other (a stale zero only costs the swap)
+                uint32_t cur = __atomic_load_n(&C.hash[slot], __ATOMIC_RELAXED);
+                if (cur == 0u) cur = atomicCAS(&C.hash[slot], 0u, (uint32_t)item + 1u);
                 if (cur == 0u) settled = true;
                 else if (kt_same_key(C.src, item, cur - 1u)) { rep = cur - 1u; settled = true; }
                 else slot = (slot + 1u) & C.hash_mask;
