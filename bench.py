@@ -381,6 +381,9 @@ def main():
                     help="feed extended coordinates (U, V, Z per point, normalised on the device)")
     ap.add_argument("--keys", type=int, default=N_KEYS,
                     help="distinct key pairs per GPU (default 4096, SURVEY.md 8d); the item count for unique keys")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured configuration); gloo only to rehearse the N > 1 logic on a box with "
+                         "fewer GPUs than ranks (ranks then share devices; the line says so and is not a measurement)")
     ap.add_argument("--lib", default=None, help="another in-tree build of the engine (A/B timing of kernel variants)")
     args = ap.parse_args()
 
@@ -390,15 +393,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run, one rank per GPU")
-    torch.cuda.set_device(local_rank)         # before any other GPU call of this process
+    rehearsal = args.backend != "nccl"
+    device_index = local_rank % max(1, torch.cuda.device_count()) if rehearsal else local_rank
+    torch.cuda.set_device(device_index)       # before any other GPU call of this process
     dist = None
     backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(args.backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         backend = dist.get_backend()
-        assert dist.get_world_size() == args.gpus and backend == "nccl", (dist.get_world_size(), backend)
+        assert dist.get_world_size() == args.gpus and backend == args.backend, (dist.get_world_size(), backend)
 
     if args.lib:
         from jubjub_schnorr_amd import _ffi
@@ -442,7 +450,8 @@ def main():
                        "global_items": head["items_per_gpu"] * world,
                        "input_format": "wire (compressed points)" if args.wire else "extended (U, V, Z)" if args.ext else "affine",
                        "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
-                       "distributed": {"backend": backend, "world_size": world},
+                       "distributed": {"backend": backend, "world_size": world,
+                                       "rehearsal_ranks_share_devices": bool(rehearsal and world > 1)},
                        "distinct_keys_per_gpu": head["distinct_keys_per_gpu"],
                        "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points; keys as SURVEY.md 8(d): "
                               "4 096 key pairs, item i signed by key i mod 4 096"},
