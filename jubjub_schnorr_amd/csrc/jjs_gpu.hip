@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {
         for (uint32_t c = 0; c < K.n_cols; ++c) {
             const key_column C = kt_col(K, (int32_t)c);
-            uint32_t slot = (uint32_t)kt_hash(C.src, item) & C.hash_mask;
+            uint32_t slot = (uint32_t)kt_hash(C.src, item, C.key_bytes) & C.hash_mask;
             uint32_t rep = (uint32_t)item;
             bool settled = false;
             // every probe either claims a slot or meets a settled one; the table has at least 2 n slots, so honest
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
                 uint32_t cur = __atomic_load_n(&C.hash[slot], __ATOMIC_RELAXED);
                 if (cur == 0u) cur = atomicCAS(&C.hash[slot], 0u, (uint32_t)item + 1u);
                 if (cur == 0u) settled = true;
-                else if (kt_same_key(C.src, item, cur - 1u)) { rep = cur - 1u; settled = true; }
+                else if (kt_same_key(C.src, item, cur - 1u, C.key_bytes)) { rep = cur - 1u; settled = true; }
                 else slot = (slot + 1u) & C.hash_mask;
             }
             if (!settled) atomicOr(&K.counters[3], 1u);
@@ -306,12 +306,14 @@ struct decode_params {
     uint8_t* ok;          // n bytes, 1/0 per item for source 0 (nullable; debug entry point)
     uint64_t n;
     dlog_tables dlog;
+    const uint32_t* skip_flag;   // nullable: the launch leaves at once when the word is non-zero (keys decoded per key instead)
 };
 __global__ __launch_bounds__(BLOCK) void dlog_table_kernel(uint32_t* pow, uint8_t* hash) {
     int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t < 7 * 256) dlog_table_entry(pow, hash, t / 256, t % 256);
 }
 __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
+    if (P.skip_flag && *P.skip_flag) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total) {
         bool all_ok = true;
@@ -324,6 +326,24 @@ __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
         if (P.bad && !all_ok) P.bad[item] = 1;
         if (P.ok) P.ok[item] = all_ok ? 1 : 0;
     }
+}
+// Wire calls on the key-table path: one decompression per distinct key, then every item copies its key's point
+// (kt_decode_key / kt_unpack_item); both leave at once when the batch does not take the key-table path.
+struct key_decode_params {
+    uint8_t* out[2];      // decoded affine column (n x 64) of key column 0 / 1
+    uint8_t* bad;         // per-item malformed flags of the call
+    dlog_tables dlog;
+};
+__global__ __launch_bounds__(BLOCK) void key_decode_kernel(key_params K, key_decode_params D) {
+    if (!K.counters[2]) return;
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, c = t / K.max_keys, id = t % K.max_keys;
+    if (c < K.n_cols && id < K.counters[c]) kt_decode_key(kt_col(K, (int32_t)c), id, c == 0 ? D.out[0] : D.out[1], D.dlog);
+}
+__global__ __launch_bounds__(BLOCK) void key_unpack_kernel(key_params K, key_decode_params D) {
+    if (!K.counters[2]) return;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
+        for (uint32_t c = 0; c < K.n_cols; ++c) kt_unpack_item(kt_col(K, (int32_t)c), item, c == 0 ? D.out[0] : D.out[1], D.bad);
 }
 // (U, V, Z) -> affine for the *_ext entry points: every lane owns the items lane, lane + lanes, ... and shares one
 // field inversion among them (normalize.h)
@@ -473,7 +493,7 @@ struct device_state {
     size_t msig_items = 0, msig_transcripts = 0;
     int grid_msig = 0;
     hipStream_t key_stream = nullptr;    // key-table path: the per-key kernels run here, beside the challenge hashes
-    hipEvent_t key_fork = nullptr, key_join = nullptr;
+    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr;
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
@@ -647,6 +667,14 @@ bool key_path_applies(const verify_params& P) {
 #endif
     return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && sl == &g->slots[0] && P.n_eq >= 1;
 }
+// The compressed key columns of a wire call: launch_verify decodes them, once per key when the key tables engage and
+// once per item otherwise, into the affine columns the scheme descriptor already points at.
+struct wire_keys {
+    uint32_t n_cols = 0;
+    fe_src comp[2];          // 32-byte encodings, in the order of the scheme's key columns (eq_desc::pk_col / gen_col)
+    uint8_t* out[2] = {};    // n x 64 affine
+    uint8_t* bad = nullptr;  // n malformed flags
+};
 // Carves the key buffers of this call out of the slot's arena and clears the hash tables and counters.
 int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     K.n = P.n;
@@ -662,7 +690,7 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     size_t slots = 1;
     while (slots < 2 * P.n) slots <<= 1;
     auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + pad(K.max_keys) +
+    const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + 2 * pad(K.max_keys) +
                            pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4) + pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
     if (int rc = ensure_keys(256 + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
@@ -671,12 +699,14 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
         C.src = cols[c];
+        C.key_bytes = 64;
         C.hash = reinterpret_cast<uint32_t*>(p); C.hash_mask = (uint32_t)(slots - 1); p += pad(slots * 4);
         HIP_TRY(hipMemsetAsync(C.hash, 0, slots * 4, s));
         C.rep = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
         C.keyid = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
         C.key_item = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * 4);
         C.key_flags = p; p += pad(K.max_keys);
+        C.key_undecodable = p; p += pad(K.max_keys);
         C.bases = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4);
         C.tables = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
     }
@@ -700,7 +730,17 @@ bool small_path_applies(const verify_params& P) {
 // verify (the equations; register-bound) and the resolve pass over the items verify queued (normally the invalid
 // ones only; the grid is sized for the batch, lanes without a queue entry leave at once).  Small batches of the
 // fixed-generator schemes take the latency path instead.  The slot has been chosen by the caller (pick_slot).
-int launch_verify(verify_params P, hipStream_t s) {
+int launch_key_decode_per_item(const verify_params& P, const wire_keys& W, const uint32_t* skip_flag, hipStream_t s) {
+    decode_params D{};
+    D.n_src = W.n_cols; D.n = P.n; D.bad = W.bad;
+    for (uint32_t c = 0; c < W.n_cols; ++c) { D.src[c] = W.comp[c]; D.out[c] = W.out[c]; }
+    D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+    D.skip_flag = skip_flag;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n)), dim3(BLOCK), 0, s, D);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) {
     if (P.n == 0) return JJS_OK;
 #if defined(JJS_PROFILING)
     P.skip_phases = g_skip_phases;
@@ -710,6 +750,8 @@ int launch_verify(verify_params P, hipStream_t s) {
     P.workspace = sl->workspace;
     if (int rc = begin_shared(s)) return rc;
     if (small_path_applies(P)) {
+        if (W)
+            if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
         if (int rc = launch_small(P, s)) return rc;
         return end_shared(s);
     }
@@ -729,16 +771,35 @@ int launch_verify(verify_params P, hipStream_t s) {
         // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
         // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
         const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
-        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
-        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
-        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, K);
+        key_params Kd = K;                       // a wire call deduplicates the 32-byte encodings
+        if (W)
+            for (uint32_t c = 0; c < K.n_cols; ++c) { Kd.col[c].src = W->comp[c]; Kd.col[c].key_bytes = 32; }
+        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
+        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
+        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
         HIP_TRY(hipEventRecord(g->key_fork, s));
         HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
-        hipLaunchKernelGGL(key_chain_kernel, dim3((K.n_cols * K.max_keys + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, g->key_stream, K);
+        const unsigned key_blocks = (K.n_cols * K.max_keys + BLOCK - 1) / BLOCK;
+        if (W) {
+            // one square root per distinct key on the key stream, while this stream decodes the key columns item by
+            // item only if the batch turned the key tables down; then every item fetches its key's point
+            key_decode_params D{};
+            for (uint32_t c = 0; c < K.n_cols; ++c) D.out[c] = W->out[c];
+            D.bad = W->bad;
+            D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+            hipLaunchKernelGGL(key_decode_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, Kd, D);
+            HIP_TRY(hipEventRecord(g->key_mid, g->key_stream));
+            if (int rc = launch_key_decode_per_item(P, *W, K.counters + 2, s)) return rc;
+            HIP_TRY(hipStreamWaitEvent(s, g->key_mid, 0));
+            hipLaunchKernelGGL(key_unpack_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd, D);
+        }
+        hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, K);
         hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_POSITIONS + BLOCK - 1) / BLOCK)),
                            dim3(BLOCK), 0, g->key_stream, K);
         HIP_TRY(hipEventRecord(g->key_join, g->key_stream));
         P.key_flag = K.counters + 2;
+    } else if (W) {
+        if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
     }
     hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P);
     if (try_keys) {
@@ -768,10 +829,10 @@ bool all_ok(Ptrs... p) {
 }
 
 extern bool g_keep_tally;
-int verify_dev_common(verify_params P, void* status, void* tally, hipStream_t s) {
+int verify_dev_common(verify_params P, void* status, void* tally, hipStream_t s, const wire_keys* W = nullptr) {
     if (status && !aligned16(status)) return fail(JJS_ERR_ARG, "status must be 16-byte aligned");
     if (tally && !g_keep_tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
-    return launch_verify(P, s);
+    return launch_verify(P, s, W);
 }
 
 int init_device(device_state& d, int ordinal) {
@@ -787,6 +848,7 @@ int init_device(device_state& d, int ordinal) {
         HIP_TRY(hipStreamCreateWithPriority(&d.key_stream, hipStreamNonBlocking, hi));
     }
     HIP_TRY(hipEventCreateWithFlags(&d.key_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.key_mid, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.key_join, hipEventDisableTiming));
     for (int i = 0; i < 33; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_up[i], hipEventDisableTiming));
@@ -865,6 +927,7 @@ void free_device(device_state& d) {
     if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
     if (d.key_stream) { (void)hipStreamSynchronize(d.key_stream); (void)hipStreamDestroy(d.key_stream); }
     if (d.key_fork) (void)hipEventDestroy(d.key_fork);
+    if (d.key_mid) (void)hipEventDestroy(d.key_mid);
     if (d.key_join) (void)hipEventDestroy(d.key_join);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = device_state{};
@@ -1280,16 +1343,18 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
-    D.n_src = 2; D.n = n; D.bad = wire_bad();
+    D.n_src = 1; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    D.src[1] = fe_src{(const uint8_t*)pk, 32, 0};   D.out[1] = wire_pts(1);      // PK
     if (int rc = launch_decode(D, s)) return rc;
+    wire_keys W;                                                                 // decoded by launch_verify
+    W.n_cols = 1; W.bad = wire_bad();
+    W.comp[0] = fe_src{(const uint8_t*)pk, 32, 0};  W.out[0] = wire_pts(1);      // PK
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
     P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s);
+    return verify_dev_common(P, status, tally, s, &W);
 }
 static int wire_double_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                               void* stream) {
@@ -1301,19 +1366,21 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
-    D.n_src = 4; D.n = n; D.bad = wire_bad();
+    D.n_src = 2; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 96, 32}; D.out[0] = wire_pts(0);      // R
     D.src[1] = fe_src{(const uint8_t*)sig, 96, 64}; D.out[1] = wire_pts(1);      // R'
-    D.src[2] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[2] = wire_pts(2);      // PK
-    D.src[3] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[3] = wire_pts(3);      // PK'
     if (int rc = launch_decode(D, s)) return rc;
+    wire_keys W;
+    W.n_cols = 2; W.bad = wire_bad();
+    W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(2);      // PK
+    W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(3);      // PK'
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_double((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3),
                                     (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o);
     P.u = fe_src{(const uint8_t*)sig, 96, 0};
     P.pre_malformed = wire_bad();
     P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s);
+    return verify_dev_common(P, status, tally, s, &W);
 }
 static int wire_vargen_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
                               void* stream) {
@@ -1325,17 +1392,19 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
     decode_params D{};
-    D.n_src = 3; D.n = n; D.bad = wire_bad();
+    D.n_src = 1; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    D.src[1] = fe_src{(const uint8_t*)pk, 64, 0};   D.out[1] = wire_pts(1);      // PK
-    D.src[2] = fe_src{(const uint8_t*)pk, 64, 32};  D.out[2] = wire_pts(2);      // generator
     if (int rc = launch_decode(D, s)) return rc;
+    wire_keys W;
+    W.n_cols = 2; W.bad = wire_bad();
+    W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(1);      // PK
+    W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(2);      // generator
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
     P.u = fe_src{(const uint8_t*)sig, 64, 0};
     P.pre_malformed = wire_bad();
     P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s);
+    return verify_dev_common(P, status, tally, s, &W);
 }
 typedef int (*wire_fn)(const void*, const void*, const void*, size_t, void*, void*, void*);
 static int wire_host(wire_fn fn, const uint8_t* sig, size_t sig_w, const uint8_t* pk, size_t pk_w, const uint8_t* m, size_t n,

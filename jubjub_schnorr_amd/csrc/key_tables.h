@@ -28,6 +28,7 @@
 // ~330 k instructions per single verification instead of ~600 k, plus ~23 k wave-instructions per distinct key.
 #pragma once
 #include "verify_core.h"
+#include "decode.h"
 
 namespace jjs {
 
@@ -49,14 +50,15 @@ constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
 
 struct key_column {
-    fe_src src;              // the key points in the caller's arrays (64 B affine, u || v)
+    fe_src src;              // the key points: 64 B affine (u || v); during the dedup of a wire call the 32 B encodings
     uint32_t* hash;          // open addressing, hash_mask + 1 slots: 0 = empty, else item index + 1
     uint32_t hash_mask;
-    uint32_t pad_;
+    uint32_t key_bytes;      // bytes of src that identify a key: 64, or 32 while src is the compressed column
     uint32_t* rep;           // [n] first item found with the same key bytes
     uint32_t* keyid;         // [n] dense id of the item's key
     uint32_t* key_item;      // [max_keys] representative item of a key
     uint8_t* key_flags;      // [max_keys] KT_KEY_*
+    uint8_t* key_undecodable;// [max_keys] wire calls: the key's encoding is not a point (decode.h)
     uint32_t* bases;         // [max_keys][KT_POSITIONS][36]: 2^(KT_WINDOW i) * P in extended coordinates
     uint32_t* tables;        // [max_keys][KT_POSITIONS][KT_TABLE_WORDS]: {0 .. 2^(KT_WINDOW-1)} * base, cached-addend form
 };
@@ -74,16 +76,17 @@ JJS_HD key_column kt_col(const key_params& K, int32_t idx) {
     const bool z = idx == 0;
     key_column c;
     c.src.base = z ? a.src.base : b.src.base; c.src.stride = z ? a.src.stride : b.src.stride; c.src.off = z ? a.src.off : b.src.off;
-    c.hash = z ? a.hash : b.hash; c.hash_mask = z ? a.hash_mask : b.hash_mask; c.pad_ = 0;
+    c.hash = z ? a.hash : b.hash; c.hash_mask = z ? a.hash_mask : b.hash_mask; c.key_bytes = z ? a.key_bytes : b.key_bytes;
     c.rep = z ? a.rep : b.rep; c.keyid = z ? a.keyid : b.keyid; c.key_item = z ? a.key_item : b.key_item;
-    c.key_flags = z ? a.key_flags : b.key_flags; c.bases = z ? a.bases : b.bases; c.tables = z ? a.tables : b.tables;
+    c.key_flags = z ? a.key_flags : b.key_flags; c.key_undecodable = z ? a.key_undecodable : b.key_undecodable; c.bases = z ? a.bases : b.bases; c.tables = z ? a.tables : b.tables;
     return c;
 }
 
-JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item) {
+JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item, uint32_t bytes) {
     uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
     for (uint32_t off = 0; off < 64; off += 32) {
+        if (off >= bytes) break;
         const words8 w = load_words(src, item, off);
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
@@ -94,10 +97,11 @@ JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item) {
     }
     return h;
 }
-JJS_HD bool kt_same_key(const fe_src& src, uint64_t a, uint64_t b) {
+JJS_HD bool kt_same_key(const fe_src& src, uint64_t a, uint64_t b, uint32_t bytes) {
     uint32_t diff = 0;
 #pragma unroll
     for (uint32_t off = 0; off < 64; off += 32) {
+        if (off >= bytes) break;
         const words8 x = load_words(src, a, off), y = load_words(src, b, off);
 #pragma unroll
         for (int i = 0; i < 8; ++i) diff |= x.w[i] ^ y.w[i];
@@ -120,6 +124,27 @@ JJS_HD ext_pt kt_load_ext(const uint32_t* src) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { p.x.l[i] = src[i]; p.y.l[i] = src[9 + i]; p.z.l[i] = src[18 + i]; p.t.l[i] = src[27 + i]; }
     return p;
+}
+
+// Wire calls (decode.h): the key columns arrive as 32-byte encodings and are deduplicated as such; a key is then
+// decompressed ONCE (one square root per key instead of one per signature) into the affine column at its
+// representative item, and every other item of the key copies the 64 bytes from there.  `out` is the decoded
+// column (n x 64), `bad` the per-item malformed flags of the call.
+JJS_HD void kt_decode_key(const key_column& C, uint32_t id, uint8_t* out, const dlog_tables& T) {
+    const uint64_t item = C.key_item[id];
+    const decoded_point d = decompress_point(load_words(C.src, item), T);
+    store_words(out, 2 * item, d.u);
+    store_words(out, 2 * item + 1, d.v);
+    C.key_undecodable[id] = d.ok ? 0 : 1;
+}
+JJS_HD void kt_unpack_item(const key_column& C, uint64_t item, uint8_t* out, uint8_t* bad) {
+    const uint32_t r = C.rep[item];
+    if (r != (uint32_t)item) {
+        const fe_src o{out, 64, 0};
+        store_words(out, 2 * item, load_words(o, r));
+        store_words(out, 2 * item + 1, load_words(o, r, 32));
+    }
+    if (C.key_undecodable[C.keyid[item]]) bad[item] = 1;
 }
 
 // one key: `is_valid` of its point, and the chain of bases

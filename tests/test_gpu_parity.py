@@ -530,6 +530,56 @@ def test_key_table_path_against_oracle(eng, scheme):
     assert (host(st2) == want[sel]).all()
 
 
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_key_table_path_wire_against_oracle(eng, scheme):
+    """The wire entry points on the key-table path: the 32-byte key encodings are deduplicated and every distinct key
+    is decompressed once (csrc/key_tables.h kt_decode_key / kt_unpack_item).  2^17 items under 512 keys, every status
+    against the C oracle: a key whose encoding is no point shared by all its items, a key replaced by its negative
+    (sign bit) on all its items, single items with undecodable or non-canonical key bytes, undecodable R."""
+    n = 1 << 17
+    b = make_batch(scheme, n, seed=9191, n_keys=512)
+    t8 = torsion_generator()
+    rng = np.random.default_rng(17)
+    from helpers import pt_bytes, to_pt
+    for k in range(1, 8):
+        i = int(rng.integers(0, n))
+        b["R"][i] = pt_bytes(o.add(to_pt(b["R"][i]), o.mul(t8, k)))
+    for i in rng.integers(0, n, 4):
+        b["u"][i] = 0xFF
+    key_col = "PKp" if scheme == "double" else ("Gen" if scheme == "vargen" else "PK")
+    _, inverse = np.unique(b[key_col], axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    def regular(i):        # an item whose key bytes are those of its key (item i uses key i mod 512), not a corrupted row
+        while not ((b[key_col][i] == b[key_col][i + 512]).all() and (b[key_col][i] == b[key_col][i + 1024]).all()):
+            i += 1
+        return i
+    i_neg, i_broken = regular(100), regular(7)
+    negated = np.where(inverse == inverse[i_neg])[0]          # every item of one key: the key replaced by its negative
+    pu, pv = to_pt(b[key_col][i_neg])
+    b[key_col][negated] = pt_bytes(((o.Q - pu) % o.Q, pv))
+    want = oracle_verify(scheme, b).copy()
+    sig, pk, m = to_wire(scheme, b)
+    nonres = np.frombuffer(next(o.le32(v) for v in range(2, 100) if o.decompress(o.le32(v)) is None), np.uint8)
+    off = 0 if scheme == "single" else 32                     # the second key column of the two-column schemes
+    broken = np.where(inverse == inverse[i_broken])[0]        # every item of another key: no square root
+    assert len(broken) > 100 and len(negated) > 100
+    pk[broken, off:off + 32] = nonres
+    want[broken] = 3
+    pk[11, :32] = np.frombuffer(o.le32(o.Q), np.uint8); want[11] = 3           # v = q on one item only
+    z = bytearray(o.compress(o.IDENTITY)); z[31] |= 0x80
+    pk[12, :32] = np.frombuffer(bytes(z), np.uint8); want[12] = 3              # u = 0 with the sign bit
+    sig[13, 32:64] = nonres; want[13] = 3                                      # R undecodable
+    st, tally = eng.verify_wire(scheme, dev(sig), dev(pk), dev(m))
+    got = host(st)
+    assert (got == want).all(), np.where(got != want)[0][:10]
+    assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    assert set(want.tolist()) == {0, 1, 2, 3} and (want[negated] != 0).all()
+    # below the key-table threshold (8 items per key) the keys are decoded item by item: same statuses
+    sel = np.concatenate([np.arange(i, n, 512)[:8] for i in range(512)] * 16)[:1 << 16]
+    st2, _ = eng.verify_wire(scheme, dev(sig[sel]), dev(pk[sel]), dev(m[sel]))
+    assert (host(st2) == want[sel]).all()
+
+
 @pytest.mark.parametrize("n_keys", [1, 2, 8191, 8192, 8193, 1 << 17])
 def test_key_table_decision_boundary(eng, n_keys):
     """2^17 + 5 single signatures under 1 ... 2^17 keys: either side of the engine's on-device decision (at most
