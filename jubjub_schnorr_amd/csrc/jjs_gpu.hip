@@ -136,9 +136,13 @@ __global__ __launch_bounds__(BLOCK) void key_assign_kernel(key_params K) {
 __global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     if (blockIdx.x == 0 && threadIdx.x == 0) {              // the decision: enough signatures per key in every column
-        bool use = K.counters[3] == 0u;                    // no probe sequence was cut short
-        for (uint32_t c = 0; c < K.n_cols; ++c) use = use && (uint64_t)K.counters[c] * KT_MIN_MULTIPLICITY <= K.n;
-        K.counters[2] = use ? 1u : 0u;
+        bool use = K.counters[3] == 0u, wide = true;       // no probe sequence was cut short
+        for (uint32_t c = 0; c < K.n_cols; ++c) {
+            use = use && (uint64_t)K.counters[c] * KT_MIN_MULTIPLICITY <= K.n;
+            wide = wide && (uint64_t)K.counters[c] * KT_WIDE_MULTIPLICITY <= K.n;
+        }
+        const uint32_t w = (wide && K.force_window != (uint32_t)KT_WINDOW_NARROW) ? KT_WINDOW_WIDE : KT_WINDOW_NARROW;
+        K.counters[2] = use ? w : 0u;                      // ... and the window width of the tables
     }
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
         for (uint32_t c = 0; c < K.n_cols; ++c) {
@@ -148,16 +152,20 @@ __global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
         }
 }
 __global__ __launch_bounds__(BLOCK, 2) void key_chain_kernel(key_params K) {
-    if (!K.counters[2]) return;
+    const int w = (int)K.counters[2];
+    if (!w) return;
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, c = t / K.max_keys, id = t % K.max_keys;
-    if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id);
+    if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id, w);
 }
+// the grid covers max_keys x KT_MAX_POSITIONS lanes per column; a batch with wide windows has fewer of both
 __global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {
-    if (!K.counters[2]) return;
+    const int w = (int)K.counters[2];
+    if (!w) return;
     const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const uint64_t per_col = (uint64_t)K.max_keys * KT_POSITIONS;
-    const uint32_t c = (uint32_t)(t / per_col), id = (uint32_t)((t % per_col) / KT_POSITIONS), pos = (uint32_t)(t % KT_POSITIONS);
-    if (c < K.n_cols && id < K.counters[c]) kt_table_lane(kt_col(K, (int32_t)c), id, pos);
+    const uint32_t positions = (uint32_t)kt_positions(w);
+    const uint64_t per_col = (uint64_t)K.max_keys * positions;
+    const uint32_t c = (uint32_t)(t / per_col), id = (uint32_t)((t % per_col) / positions), pos = (uint32_t)(t % positions);
+    if (c < K.n_cols && id < K.counters[c]) kt_table_lane(kt_col(K, (int32_t)c), id, pos, w);
 }
 __global__ __launch_bounds__(BLOCK, 2) void key_verify_kernel(verify_params P, key_params K) {
     if (!keyed_mode(P)) return;
@@ -564,6 +572,7 @@ uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_pr
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
 int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
+int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
 #endif
 
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
@@ -679,6 +688,9 @@ struct wire_keys {
 int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     K.n = P.n;
     K.max_keys = (uint32_t)(P.n / KT_MIN_MULTIPLICITY);
+#if defined(JJS_PROFILING)
+    K.force_window = (uint32_t)g_force_window;
+#endif
     // key columns: PK of every equation, and the generator where it is per-item data
     fe_src cols[2];
     uint32_t n_cols = 0;
@@ -691,7 +703,7 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     while (slots < 2 * P.n) slots <<= 1;
     auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + 2 * pad(K.max_keys) +
-                           pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4) + pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
+                           pad(kt_base_words_for(P.n) * 4) + pad(kt_table_words_for(P.n) * 4);
     if (int rc = ensure_keys(256 + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
@@ -707,8 +719,8 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
         C.key_item = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * 4);
         C.key_flags = p; p += pad(K.max_keys);
         C.key_undecodable = p; p += pad(K.max_keys);
-        C.bases = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_BASE_WORDS * 4);
-        C.tables = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * KT_POSITIONS * KT_TABLE_WORDS * 4);
+        C.bases = reinterpret_cast<uint32_t*>(p); p += pad(kt_base_words_for(P.n) * 4);
+        C.tables = reinterpret_cast<uint32_t*>(p); p += pad(kt_table_words_for(P.n) * 4);
     }
     return JJS_OK;
 }
@@ -794,7 +806,7 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
             hipLaunchKernelGGL(key_unpack_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd, D);
         }
         hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, K);
-        hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_POSITIONS + BLOCK - 1) / BLOCK)),
+        hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
                            dim3(BLOCK), 0, g->key_stream, K);
         HIP_TRY(hipEventRecord(g->key_join, g->key_stream));
         P.key_flag = K.counters + 2;
@@ -1791,7 +1803,8 @@ int jjs_debug_skip_phases(unsigned mask) {
 int jjs_debug_force_path(int which) {
     std::lock_guard<std::mutex> lock(L.mu);
     g_force_path = which & 3;                       // 0 by size and keys, 1 throughput (key tables allowed), 2 latency, 3 throughput without key tables
-    g_force_positions = (which >> 4) == 4 || (which >> 4) == 8 ? (which >> 4) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
+    g_force_positions = ((which >> 4) & 15) == 4 || ((which >> 4) & 15) == 8 ? ((which >> 4) & 15) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
+    g_force_window = (which >> 8) == KT_WINDOW_NARROW ? (which >> 8) : 0;   // 0x500: narrow key-table windows whatever the keys
     return JJS_OK;
 }
 int jjs_debug_allow_virtual_devices(int allow) {

@@ -15,10 +15,10 @@
 //                 happens when some key needed more than KT_MAX_PROBES probes (keys crafted to collide in the hash
 //                 table must not be able to make the call slow) or when the key arena cannot be allocated.
 //   3. per key    `is_valid` of the key point ONCE per key (src/keys/public.rs:159-164: canonical, on the curve,
-//                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(W i) * P and the tables
-//                 {0 .. 2^(W-1)} * B_i for signed W-bit digits (W = KT_WINDOW).
+//                 not the identity, torsion-free by the pairing test), the chain B_i = 2^(w i) * P and the tables
+//                 {0 .. 2^(w-1)} * B_i for signed w-bit digits (w = 5 or 6, chosen with the decision).
 //   4. per item   challenge hash as before (prepare_item in keyed mode: no half-size scalars, no combined test);
-//                 then  acc = sum_i digit_i(c) * B_i  (51 additions for W = 5, no doubling) + u*G from the fixed-base comb
+//                 then  acc = sum_i digit_i(c) * B_i  (51 or 43 additions, no doubling) + u*G from the fixed-base comb
 //                 (16 additions), compared with R projectively: the reference's own equation u*G + c*PK == R
 //                 (src/keys/public.rs:128-130), computed exactly by the complete addition law.
 //   Subgroup membership of R: if the equation holds and the key is torsion-free then R = u*G + c*PK is in the
@@ -32,22 +32,35 @@
 
 namespace jjs {
 
-// Signed digits of KT_WINDOW bits: a scalar below 2^252 has KT_POSITIONS of them (the top one unsigned and small),
-// a table holds the multiples 0 .. 2^(KT_WINDOW-1) of its base.  Wider windows trade per-key work and memory
-// (positions x entries) for per-signature additions: 4 -> 64 additions / 83 KB per key, 5 -> 51 / 125 KB,
-// 6 -> 43 / 204 KB.  Measured on the SURVEY.md 8(d) workload (~128 signatures per key): profiles/r02*_kt_window.
-#ifndef JJS_KT_WINDOW
-#define JJS_KT_WINDOW 5
-#endif
-constexpr int KT_WINDOW = JJS_KT_WINDOW;
-constexpr int KT_POSITIONS = (252 + KT_WINDOW) / KT_WINDOW;
-constexpr int KT_ENTRIES = (1 << (KT_WINDOW - 1)) + 1;
-constexpr int KT_TABLE_WORDS = KT_ENTRIES * ENTRY_WORDS;
-static_assert(KT_WINDOW >= 4 && KT_WINDOW <= 6, "digit extraction assumes a digit spans at most two words");
+// Signed digits of w bits: a scalar below 2^252 has kt_positions(w) of them (the top one unsigned and small), a table
+// holds the multiples 0 .. 2^(w-1) of its base.  Wider windows trade per-key work and memory (positions x entries)
+// for per-signature additions: 4 -> 64 additions / 83 KB per key, 5 -> 51 / 125 KB, 6 -> 43 / 204 KB.  The width is
+// chosen on the device with the decision itself (key_spread_kernel): 6 bits when every column has at least
+// KT_WIDE_MULTIPLICITY signatures per key (the 560 extra table additions per key are then repaid by the 8 saved per
+// signature, with margin for the larger tables' cache footprint), else 5.  Measured on SURVEY.md 8(d)'s workload (256
+// signatures per key; 2^20 single / double / var-gen, ms): 4 bits 11.01 / 19.82 / 14.75, 5 bits 11.00 / 19.06 / 13.98,
+// 6 bits 10.81 / 18.59 / 13.26.
+constexpr int KT_WINDOW_NARROW = 5, KT_WINDOW_WIDE = 6;
+constexpr uint32_t KT_WIDE_MULTIPLICITY = 128;
+JJS_HD constexpr int kt_positions(int w) { return (252 + w) / w; }
+JJS_HD constexpr int kt_entries(int w) { return (1 << (w - 1)) + 1; }
+JJS_HD constexpr int kt_table_words(int w) { return kt_entries(w) * ENTRY_WORDS; }
+constexpr int KT_MAX_POSITIONS = kt_positions(KT_WINDOW_NARROW);
+static_assert(KT_WINDOW_NARROW >= 4 && KT_WINDOW_WIDE <= 6 && KT_WINDOW_NARROW < KT_WINDOW_WIDE, "digit extraction assumes a digit spans at most two words");
 constexpr uint32_t KT_MIN_MULTIPLICITY = 16;     // the tables pay from ~6 signatures per key; margin for their memory
 constexpr uint32_t KT_MAX_PROBES = 128;          // hash-table probes per key before the batch gives up on key tables
 constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
+// arena words per column for a batch of n items: narrow windows for up to n / KT_MIN_MULTIPLICITY keys, wide ones for up
+// to n / KT_WIDE_MULTIPLICITY
+JJS_HD constexpr size_t kt_max(size_t a, size_t b) { return a > b ? a : b; }
+JJS_HD constexpr size_t kt_base_words_for(size_t n) {
+    return kt_max((n / KT_MIN_MULTIPLICITY) * kt_positions(KT_WINDOW_NARROW), (n / KT_WIDE_MULTIPLICITY) * kt_positions(KT_WINDOW_WIDE)) * KT_BASE_WORDS;
+}
+JJS_HD constexpr size_t kt_table_words_for(size_t n) {
+    return kt_max((n / KT_MIN_MULTIPLICITY) * kt_positions(KT_WINDOW_NARROW) * kt_table_words(KT_WINDOW_NARROW),
+                  (n / KT_WIDE_MULTIPLICITY) * kt_positions(KT_WINDOW_WIDE) * kt_table_words(KT_WINDOW_WIDE));
+}
 
 struct key_column {
     fe_src src;              // the key points: 64 B affine (u || v); during the dedup of a wire call the 32 B encodings
@@ -59,13 +72,15 @@ struct key_column {
     uint32_t* key_item;      // [max_keys] representative item of a key
     uint8_t* key_flags;      // [max_keys] KT_KEY_*
     uint8_t* key_undecodable;// [max_keys] wire calls: the key's encoding is not a point (decode.h)
-    uint32_t* bases;         // [max_keys][KT_POSITIONS][36]: 2^(KT_WINDOW i) * P in extended coordinates
-    uint32_t* tables;        // [max_keys][KT_POSITIONS][KT_TABLE_WORDS]: {0 .. 2^(KT_WINDOW-1)} * base, cached-addend form
+    uint32_t* bases;         // [keys][positions][36]: 2^(w i) * P in extended coordinates (w = the window width of this batch)
+    uint32_t* tables;        // [keys][positions][table words]: {0 .. 2^(w-1)} * base, cached-addend form
 };
 struct key_params {
     uint32_t n_cols, max_keys;
     key_column col[2];
-    uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 1 = key-table path; [3] a probe sequence overflowed
+    uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 0 = throughput path, else the window width of
+                             // the key-table path; [3] a probe sequence overflowed
+    uint32_t force_window;   // profiling build only (0 in the product): KT_WINDOW_NARROW = never the wide windows
     uint64_t n;
 };
 
@@ -109,11 +124,11 @@ JJS_HD bool kt_same_key(const fe_src& src, uint64_t a, uint64_t b, uint32_t byte
     return diff == 0;
 }
 
-JJS_HD uint32_t* kt_base(const key_column& C, uint32_t id, uint32_t pos) {
-    return C.bases + ((size_t)id * KT_POSITIONS + pos) * KT_BASE_WORDS;
+JJS_HD uint32_t* kt_base(const key_column& C, uint32_t id, uint32_t pos, int w) {
+    return C.bases + ((size_t)id * kt_positions(w) + pos) * KT_BASE_WORDS;
 }
-JJS_HD uint32_t* kt_table(const key_column& C, uint32_t id, uint32_t pos) {
-    return C.tables + ((size_t)id * KT_POSITIONS + pos) * KT_TABLE_WORDS;
+JJS_HD uint32_t* kt_table(const key_column& C, uint32_t id, uint32_t pos, int w) {
+    return C.tables + ((size_t)id * kt_positions(w) + pos) * kt_table_words(w);
 }
 JJS_HD void kt_store_ext(uint32_t* dst, const ext_pt& p) {
 #pragma unroll
@@ -148,7 +163,7 @@ JJS_HD void kt_unpack_item(const key_column& C, uint64_t item, uint8_t* out, uin
 }
 
 // one key: `is_valid` of its point, and the chain of bases
-JJS_HD void kt_chain_key(const key_column& C, uint32_t id) {
+JJS_HD void kt_chain_key(const key_column& C, uint32_t id, int w) {
     const uint64_t item = C.key_item[id];
     const words8 uw = load_words(C.src, item), vw = load_words(C.src, item, 32);
     const bool canonical = words_lt(uw, JJS_Q_WORDS) && words_lt(vw, JJS_Q_WORDS);
@@ -156,76 +171,83 @@ JJS_HD void kt_chain_key(const key_column& C, uint32_t id) {
     const bool valid = canonical && point_on_curve_not_identity(pu, pv) && is_torsion_free(pu, pv);
     C.key_flags[id] = (uint8_t)((canonical ? 0u : KT_KEY_MALFORMED) | (valid ? KT_KEY_VALID : 0u));
     ext_pt p = ext_from_affine(pu, pv);
-    kt_store_ext(kt_base(C, id, 0), p);
-    for (uint32_t pos = 1; pos < (uint32_t)KT_POSITIONS; ++pos) {
+    kt_store_ext(kt_base(C, id, 0, w), p);
+    const uint32_t positions = (uint32_t)kt_positions(w);
+    for (uint32_t pos = 1; pos < positions; ++pos) {
 #pragma unroll 1
-        for (int j = 0; j < KT_WINDOW; ++j) p = ext_double(p, j == KT_WINDOW - 1);
-        kt_store_ext(kt_base(C, id, pos), p);
+        for (int j = 0; j < w; ++j) p = ext_double(p, j == w - 1);
+        kt_store_ext(kt_base(C, id, pos, w), p);
     }
 }
 
-// table[j] = j * P for j = 0 .. KT_ENTRIES-1, P in extended coordinates (the cached-addend entries keep their Z)
-JJS_HD void kt_build_table(uint32_t* tab, const ext_pt& p1) {
+// table[j] = j * P for j = 0 .. entries-1, P in extended coordinates (the cached-addend entries keep their Z)
+JJS_HD void kt_build_table(uint32_t* tab, const ext_pt& p1, int entries) {
     const niels_pt n1 = to_niels(p1);
     store_niels(tab, niels_identity());
     store_niels(tab + ENTRY_WORDS, n1);
     ext_pt acc = ext_double(p1, true);
     store_niels(tab + 2 * ENTRY_WORDS, to_niels(acc));
-    for (int j = 3; j < KT_ENTRIES; ++j) {
+    for (int j = 3; j < entries; ++j) {
         acc = ext_add_niels(acc, n1, false, true);
         store_niels(tab + j * ENTRY_WORDS, to_niels(acc));
     }
 }
-JJS_HD void kt_table_lane(const key_column& C, uint32_t id, uint32_t pos) {
-    kt_build_table(kt_table(C, id, pos), kt_load_ext(kt_base(C, id, pos)));
+JJS_HD void kt_table_lane(const key_column& C, uint32_t id, uint32_t pos, int w) {
+    kt_build_table(kt_table(C, id, pos, w), kt_load_ext(kt_base(C, id, pos, w)), kt_entries(w));
 }
 
-// s + sum_{i < POSITIONS-1} 2^(W-1) * 2^(W i): digit i of the sum, minus 2^(W-1), is signed digit i of s; the top
+// s + sum_{i < positions-1} 2^(w-1) * 2^(w i): digit i of the sum, minus 2^(w-1), is signed digit i of s; the top
 // digit is unsigned (at most 5 for s < 2^252)
-JJS_HD constexpr uint32_t kt_recode_word(int w) {
+JJS_HD constexpr uint32_t kt_recode_word(int w, int word) {
     uint32_t v = 0;
-    for (int i = 0; i < KT_POSITIONS - 1; ++i) {
-        const int bit = KT_WINDOW * i + KT_WINDOW - 1;
-        if ((bit >> 5) == w) v |= 1u << (bit & 31);
+    for (int i = 0; i < kt_positions(w) - 1; ++i) {
+        const int bit = w * i + w - 1;
+        if ((bit >> 5) == word) v |= 1u << (bit & 31);
     }
     return v;
 }
-JJS_HD words8 kt_recode(const words8& s) {
-    constexpr uint32_t K[8] = {kt_recode_word(0), kt_recode_word(1), kt_recode_word(2), kt_recode_word(3),
-                               kt_recode_word(4), kt_recode_word(5), kt_recode_word(6), kt_recode_word(7)};
+JJS_HD words8 kt_recode(const words8& s, int w) {
+    constexpr uint32_t KN[8] = {kt_recode_word(KT_WINDOW_NARROW, 0), kt_recode_word(KT_WINDOW_NARROW, 1), kt_recode_word(KT_WINDOW_NARROW, 2),
+                                kt_recode_word(KT_WINDOW_NARROW, 3), kt_recode_word(KT_WINDOW_NARROW, 4), kt_recode_word(KT_WINDOW_NARROW, 5),
+                                kt_recode_word(KT_WINDOW_NARROW, 6), kt_recode_word(KT_WINDOW_NARROW, 7)};
+    constexpr uint32_t KW[8] = {kt_recode_word(KT_WINDOW_WIDE, 0), kt_recode_word(KT_WINDOW_WIDE, 1), kt_recode_word(KT_WINDOW_WIDE, 2),
+                                kt_recode_word(KT_WINDOW_WIDE, 3), kt_recode_word(KT_WINDOW_WIDE, 4), kt_recode_word(KT_WINDOW_WIDE, 5),
+                                kt_recode_word(KT_WINDOW_WIDE, 6), kt_recode_word(KT_WINDOW_WIDE, 7)};
+    const bool wide = w == KT_WINDOW_WIDE;
     words8 r;
     uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint64_t t = (uint64_t)s.w[i] + K[i] + carry;
+        const uint64_t t = (uint64_t)s.w[i] + (wide ? KW[i] : KN[i]) + carry;
         r.w[i] = (uint32_t)t;
         carry = t >> 32;
     }
     return r;
 }
-// acc + (digit `pos` of the recoded scalar) * base_pos; pos is wave-uniform, the digit is per lane
-JJS_HD ext_pt kt_add_digit(const ext_pt& acc, const uint32_t* tab, const words8& sc, int pos) {
-    const int bit = KT_WINDOW * pos, wi = bit >> 5, sh = bit & 31;
+// acc + (digit `pos` of the recoded scalar) * base_pos; pos and w are wave-uniform, the digit is per lane
+JJS_HD ext_pt kt_add_digit(const ext_pt& acc, const uint32_t* tab, const words8& sc, int pos, int w) {
+    const int bit = w * pos, wi = bit >> 5, sh = bit & 31;
     uint32_t v = word_at(sc, wi) >> sh;
-    if (sh + KT_WINDOW > 32) v |= word_at(sc, wi + 1 > 7 ? 7 : wi + 1) << (32 - sh);
-    const uint32_t raw = v & ((1u << KT_WINDOW) - 1u);
-    const bool top = pos == KT_POSITIONS - 1;
-    const int d = top ? (int)(word_at(sc, wi) >> sh) : (int)raw - (1 << (KT_WINDOW - 1));
+    if (sh + w > 32) v |= word_at(sc, wi + 1 > 7 ? 7 : wi + 1) << (32 - sh);
+    const uint32_t raw = v & ((1u << w) - 1u);
+    const bool top = pos == kt_positions(w) - 1;
+    const int d = top ? (int)(word_at(sc, wi) >> sh) : (int)raw - (1 << (w - 1));
     const bool neg = d < 0;
     uint32_t idx = (uint32_t)(neg ? -d : d);
-    idx = idx >= (uint32_t)KT_ENTRIES ? (uint32_t)KT_ENTRIES - 1u : idx;     // out-of-range (malformed) scalars only
+    idx = idx >= (uint32_t)kt_entries(w) ? (uint32_t)kt_entries(w) - 1u : idx;     // out-of-range (malformed) scalars only
     return ext_add_niels(acc, load_niels(tab + idx * ENTRY_WORDS), neg, true);
 }
-// acc + s * P for the key `id` of column C, s < 2^252: KT_POSITIONS additions, no doubling.  T of the result is valid.
-JJS_HD ext_pt kt_add_scalar(ext_pt acc, const key_column& C, uint32_t id, const words8& s) {
-    const words8 sc = kt_recode(s);
-    for (int pos = KT_POSITIONS - 1; pos >= 0; --pos) acc = kt_add_digit(acc, kt_table(C, id, (uint32_t)pos), sc, pos);
+// acc + s * P for the key `id` of column C, s < 2^252: one addition per position, no doubling.  T of the result is valid.
+JJS_HD ext_pt kt_add_scalar(ext_pt acc, const key_column& C, uint32_t id, const words8& s, int w) {
+    const words8 sc = kt_recode(s, w);
+    for (int pos = kt_positions(w) - 1; pos >= 0; --pos) acc = kt_add_digit(acc, kt_table(C, id, (uint32_t)pos, w), sc, pos, w);
     return acc;
 }
 
 // The equations of one item through the key tables (step 4 above).  r = prepare_item's record in keyed mode:
 // challenge, malformed (u, m, the R points), valid (every R point on the curve and not the identity).
 JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint64_t item, const prep_record& r) {
+    const int w = (int)*P.key_flag;                  // the window width this batch's tables were built with
     const words8 u = load_words(P.u, item);
     bool keys_valid = true, keys_malformed = false, eq_ok = true;
     for (uint32_t e = 0; e < P.n_eq; ++e) {
@@ -238,7 +260,7 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
             keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
             // JJS_SKIP bit 4 (profiling build only, constant false in the product): the lanes share 64 keys' tables
             // (8 MB, cache-resident, no hot spot) -- what the gathers cost
-            acc = kt_add_scalar(acc, C, JJS_SKIP(P, 16u) ? (id & 63u) : id, r.c);     // c * PK
+            acc = kt_add_scalar(acc, C, JJS_SKIP(P, 16u) ? (id & 63u) : id, r.c, w);     // c * PK
         }
         if (E.comb) {
             acc = add_comb(acc, E.comb, u);                                   // + u * G (G')
@@ -247,7 +269,7 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
             const uint32_t id = C.keyid[item], f = C.key_flags[id];
             keys_valid = keys_valid && (f & KT_KEY_VALID) != 0;
             keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
-            acc = kt_add_scalar(acc, C, id, u);                               // + u * Gen
+            acc = kt_add_scalar(acc, C, id, u, w);                             // + u * Gen
         }
         const fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
         eq_ok = ext_eq_affine(acc, ru, rv) && eq_ok;

@@ -35,6 +35,15 @@ def main() -> None:
                 assert t2.cpu().numpy().tolist() == tally.cpu().numpy().tolist()
                 st_h, tally_h = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])           # host buffers
                 assert st_h.tolist() == want.tolist() and tally_h.tolist() == tally.cpu().numpy().tolist()
+    # key-table path: both window widths on the same batch (218 signatures per key: the product takes the wide windows)
+    for scheme in ("single", "double", "vargen"):
+        b = make_batch(scheme, 65536 + 37, seed=808, n_keys=300)
+        want = oracle_verify(scheme, b)
+        for path in (0, 0x500):
+            assert lib.jjs_debug_force_path(path) == 0
+            st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
+            assert (st.cpu().numpy() == want).all(), (scheme, path)
+            assert tally.cpu().numpy().tolist() == [int((want == k).sum()) for k in range(4)], (scheme, path)
     lib.jjs_debug_force_path(0)
     print("FORCEPATH OK")
 

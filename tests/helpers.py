@@ -269,3 +269,41 @@ def batch_to_extended(scheme: str, b: dict, seed: int = 3) -> list:
     """The arrays of a batch in ABI order with every point array turned into extended coordinates."""
     rng = np.random.default_rng(seed)
     return [to_extended(b[k], rng) if b[k].shape[1] == 64 else b[k] for k in ARG_ORDER[scheme]]
+
+
+def crafted_collision_batch(n_good=1 << 17, n_bad=2000):
+    """A single-signature batch whose last n_bad public keys are distinct byte strings built to land on ONE slot of the
+    engine's key hash table (csrc/key_tables.h: the hash is public and unkeyed, so a sender can do this)."""
+    M64 = (1 << 64) - 1
+    C = 0xFF51AFD7ED558CCD
+    C_INV = pow(C, -1, 1 << 64)
+
+    def state_before_last_chunk(key56: bytes) -> int:
+        h = 0x9E3779B97F4A7C15
+        for k in range(7):
+            h ^= int.from_bytes(key56[8 * k:8 * k + 8], "little")
+            h = (h * C) & M64
+            h ^= h >> 29
+        return h
+
+    n = n_good + n_bad
+    slots = 1
+    while slots < 2 * n:
+        slots <<= 1
+    mask = slots - 1
+    b = make_batch("single", n, seed=31337, n_keys=512)
+    rng = np.random.default_rng(5)
+    target = 0x2A5A5 & mask
+    for i in range(n_good, n):
+        prefix = rng.bytes(56)
+        t_hi = int.from_bytes(rng.bytes(8), "little") & ~mask & M64
+        t = t_hi | (target ^ ((t_hi >> 29) & mask))
+        x = ((t * C_INV) & M64) ^ state_before_last_chunk(prefix)
+        key = prefix + x.to_bytes(8, "little")
+        # the engine's hash of these 64 bytes ends on `target`
+        h = state_before_last_chunk(prefix) ^ x
+        h = (h * C) & M64
+        h ^= h >> 29
+        assert (h & 0xFFFFFFFF) & mask == target
+        b["PK"][i] = np.frombuffer(key, np.uint8)
+    return b

@@ -95,7 +95,9 @@ static void run_small(verify_params P, uint32_t positions) {
 
 // the key-table path of csrc/key_tables.h: keys deduplicated with a std::map (the device uses a hash table with
 // the same byte-exact notion of "same key"), everything else through the product's own functions
+static int g_key_window = KT_WINDOW_NARROW;      // jjs_host_set_key_window: both widths of the product run here
 static void run_keyed(verify_params P) {
+    const int w = g_key_window;
     key_params K{};
     K.n = P.n; K.max_keys = (uint32_t)P.n + 1;
     fe_src cols[2]; uint32_t n_cols = 0;
@@ -120,16 +122,16 @@ static void run_keyed(verify_params P) {
         }
         const size_t nk = key_item[c].size();
         counters[c] = (uint32_t)nk;
-        flags[c].resize(nk + 1); bases[c].resize(nk * KT_POSITIONS * KT_BASE_WORDS + 4); tables[c].resize(nk * KT_POSITIONS * KT_TABLE_WORDS + 8);
+        flags[c].resize(nk + 1); bases[c].resize(nk * kt_positions(w) * KT_BASE_WORDS + 4); tables[c].resize(nk * kt_positions(w) * kt_table_words(w) + 8);
         C.keyid = keyid[c].data(); C.key_item = key_item[c].data(); C.key_flags = flags[c].data();
         C.bases = bases[c].data();
         C.tables = (uint32_t*)(((uintptr_t)tables[c].data() + 15) & ~(uintptr_t)15);
         for (uint32_t id = 0; id < nk; ++id) {
-            kt_chain_key(C, id);
-            for (uint32_t pos = 0; pos < (uint32_t)KT_POSITIONS; ++pos) kt_table_lane(C, id, pos);
+            kt_chain_key(C, id, w);
+            for (uint32_t pos = 0; pos < (uint32_t)kt_positions(w); ++pos) kt_table_lane(C, id, pos, w);
         }
     }
-    counters[2] = 1;
+    counters[2] = (uint32_t)w;
     P.key_flag = &counters[2];
     for (uint64_t i = 0; i < P.n; ++i) {
         uint32_t st = kt_finish_item(P, K, i, prepare_item(P, i));
@@ -141,6 +143,11 @@ static void run_keyed(verify_params P) {
 
 extern "C" {
 
+int jjs_host_set_key_window(int w) {
+    if (w != KT_WINDOW_NARROW && w != KT_WINDOW_WIDE) return -1;
+    g_key_window = w;
+    return 0;
+}
 int jjs_host_verify_keyed_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                                  uint8_t* status, uint64_t* tally) {
     ensure_tables();

@@ -158,12 +158,13 @@ def verify_small(scheme, b, positions=4):
     return st, tally
 
 
-def verify_keyed(scheme, b):
-    """The key-table path (csrc/key_tables.h) on the CPU build."""
+def verify_keyed(scheme, b, window=5):
+    """The key-table path (csrc/key_tables.h) on the CPU build, with 5- or 6-bit windows."""
     from helpers import ARG_ORDER
     args = [_c(b[k]) for k in ARG_ORDER[scheme]]
     n = len(args[0])
     st = np.empty(n, np.uint8); tally = np.zeros(4, np.uint64)
+    assert load().jjs_host_set_key_window(int(window)) == 0
     fn = getattr(load(), "jjs_host_verify_keyed_" + scheme)
     fn(*[_p(a) for a in args], ctypes.c_size_t(n), _p(st), _p(tally))
     return st, tally

@@ -580,11 +580,11 @@ def test_key_table_path_wire_against_oracle(eng, scheme):
     assert (host(st2) == want[sel]).all()
 
 
-@pytest.mark.parametrize("n_keys", [1, 2, 8191, 8192, 8193, 1 << 17])
+@pytest.mark.parametrize("n_keys", [1, 2, 1024, 1025, 8191, 8192, 8193, 1 << 17])
 def test_key_table_decision_boundary(eng, n_keys):
-    """2^17 + 5 single signatures under 1 ... 2^17 keys: either side of the engine's on-device decision (at most
-    n / 16 distinct keys -> key tables, else the throughput path), one key for every item (every lane on one hash
-    slot), statuses by construction plus an oracle sample."""
+    """2^17 + 5 single signatures under 1 ... 2^17 keys: either side of the engine's on-device decisions (at most
+    n / 128 distinct keys -> key tables with 6-bit windows, at most n / 16 -> 5-bit windows, else the throughput
+    path), one key for every item (every lane on one hash slot), statuses by construction plus an oracle sample."""
     import torch
     n = (1 << 17) + 5
     gen = torch.Generator(device="cpu").manual_seed(4000 + n_keys)
@@ -613,52 +613,23 @@ def test_keys_crafted_to_collide_in_the_hash_table(eng):
     """2 000 distinct public-key byte strings built to land on ONE slot of the engine's key hash table (the hash of
     csrc/key_tables.h is public and unkeyed, so a sender can do this): the probe sequences are cut at KT_MAX_PROBES and
     the batch takes the throughput path; the call stays fast and every status is still the oracle's."""
-    M64 = (1 << 64) - 1
-    C = 0xFF51AFD7ED558CCD
-    C_INV = pow(C, -1, 1 << 64)
-
-    def state_before_last_chunk(key56: bytes) -> int:
-        h = 0x9E3779B97F4A7C15
-        for k in range(7):
-            h ^= int.from_bytes(key56[8 * k:8 * k + 8], "little")
-            h = (h * C) & M64
-            h ^= h >> 29
-        return h
-
-    n_good, n_bad = 1 << 17, 2000
-    n = n_good + n_bad
-    slots = 1
-    while slots < 2 * n:
-        slots <<= 1
-    mask = slots - 1
-    b = make_batch("single", n, seed=31337, n_keys=512)
-    rng = np.random.default_rng(5)
-    target = 0x2A5A5 & mask
-    for i in range(n_good, n):
-        prefix = rng.bytes(56)
-        t_hi = int.from_bytes(rng.bytes(8), "little") & ~mask & M64
-        t = t_hi | (target ^ ((t_hi >> 29) & mask))
-        x = ((t * C_INV) & M64) ^ state_before_last_chunk(prefix)
-        key = prefix + x.to_bytes(8, "little")
-        # the engine's hash of these 64 bytes ends on `target`
-        h = state_before_last_chunk(prefix) ^ x
-        h = (h * C) & M64
-        h ^= h >> 29
-        assert (h & 0xFFFFFFFF) & mask == target
-        b["PK"][i] = np.frombuffer(key, np.uint8)
+    from helpers import crafted_collision_batch
+    b = crafted_collision_batch()
     want = oracle_verify("single", b)
     import time
     import torch
     args = [dev(b[k]) for k in ARG_ORDER["single"]]
     eng.verify("single", *args)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st, tally = eng.verify("single", *args)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1.0
+    for _ in range(3):            # the fastest of three: a pause of the test process itself is not the engine's
+        t0 = time.perf_counter()
+        st, tally = eng.verify("single", *args)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     assert (host(st) == want).all()
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
-    assert dt < 0.05, dt          # ~3 ms on the throughput path; an unbounded chain of 2 000 keys would not matter yet,
+    assert dt < 0.05, dt          # ~5 ms on the throughput path; an unbounded chain of 2 000 keys would not matter yet,
     #                               a chain of 10^6 would: the bound is what keeps the worst case at this cost
 
 

@@ -361,16 +361,18 @@ def test_small_batch_path_matches_oracle(scheme, positions):
 
 
 # ---- key-table path (csrc/key_tables.h) -------------------------------------------------------------------
+@pytest.mark.parametrize("window", [5, 6])
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
-def test_key_table_path_matches_oracle(scheme):
-    """Per-key validity and window tables, per-item additions only: the same statuses as the oracle on a mixed batch
-    with few keys, on the hand-built edge cases (every item its own key) and on the torsion grid."""
+def test_key_table_path_matches_oracle(scheme, window):
+    """Per-key validity and window tables (both widths the engine chooses between), per-item additions only: the same
+    statuses as the oracle on a mixed batch with few keys, on the hand-built edge cases (every item its own key) and
+    on the torsion grid."""
     b = make_batch(scheme, 60, seed=83, n_keys=4)
     want = oracle_verify(scheme, b)
-    st, tally = hl.verify_keyed(scheme, b)
+    st, tally = hl.verify_keyed(scheme, b, window)
     assert st.tolist() == want.tolist()
     assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
     b = edge_cases(scheme)
-    assert hl.verify_keyed(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
+    assert hl.verify_keyed(scheme, b, window)[0].tolist() == oracle_verify(scheme, b).tolist()
     b = torsion_grid(scheme, reps=1, extra=0 if scheme == "single" else 30)
-    assert hl.verify_keyed(scheme, b)[0].tolist() == oracle_verify(scheme, b).tolist()
+    assert hl.verify_keyed(scheme, b, window)[0].tolist() == oracle_verify(scheme, b).tolist()
