@@ -454,10 +454,11 @@ __global__ __launch_bounds__(BLOCK) void dbg_half_scalars_kernel(const uint8_t* 
 // ---------------------------------------------------------------------------------------------
 // Per-device state: everything a launch on that device needs (tables, per-lane workspace, scratch).
 // What one verification call in flight needs beside its inputs.  A device has one big slot (slot 0: the workspace
-// of the persistent verify grid, used by every large call and by the signer / multisig kernels) and
-// N_SMALL_SLOTS small ones, handed out round-robin to calls of at most SMALL_SLOT_ITEMS items: calls in different
-// slots touch disjoint buffers and are not ordered against each other, so small calls issued on different
-// streams overlap on the device; calls that share a slot are ordered by its event.
+// of the persistent verify grid, used by every large call and by the signer / multisig kernels), N_SMALL_SLOTS
+// small ones, handed out round-robin to calls of at most SMALL_SLOT_ITEMS items, and N_MEDIUM_SLOTS medium ones for
+// calls of at most MEDIUM_SLOT_ITEMS: calls in different slots touch disjoint buffers and are not ordered against
+// each other, so small and medium calls issued on different streams overlap on the device; calls that share a slot
+// are ordered by its event.
 struct call_slot {
     uint32_t* workspace = nullptr;    // WS_WORDS_PER_LANE words per lane of the verify grid
     int grid_verify = 0;              // blocks of verify_kernel that fit this workspace
@@ -475,6 +476,12 @@ struct call_slot {
 };
 constexpr int N_SMALL_SLOTS = 3;
 constexpr size_t SMALL_SLOT_ITEMS = 16384;
+// Calls of up to MEDIUM_SLOT_ITEMS items take one of N_MEDIUM_SLOTS medium slots in turn: such a call is a few waves
+// per SIMD at most and is bound by the latency of one signature (~1.7 ms), so calls on different streams overlap almost
+// freely.  A medium slot has everything the big one has (workspace, key arena) for its size.
+constexpr int N_MEDIUM_SLOTS = 3;
+constexpr size_t MEDIUM_SLOT_ITEMS = 131072;
+constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS;
 // largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
 // path is faster (tools/batch_size_curve.py)
 constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
@@ -485,8 +492,8 @@ constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARG
 
 struct device_state {
     int device = -1;               // HIP device ordinal
-    call_slot slots[1 + N_SMALL_SLOTS];
-    unsigned next_small = 0;
+    call_slot slots[N_SLOTS];          // [0] big, then the small ones, then the medium ones
+    unsigned next_small = 0, next_medium = 0;
     hipStream_t stream = nullptr;  // used by the host-buffer entry points
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
@@ -578,6 +585,7 @@ int g_force_window = 0;           // ... 5: narrow windows on the key-table path
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
 void pick_slot(size_t n) {
     if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
+    else if (n <= MEDIUM_SLOT_ITEMS) { sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium]; g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS; }
     else sl = &g->slots[0];
 }
 void big_slot() { sl = &g->slots[0]; }
@@ -668,13 +676,13 @@ int ensure_keys(size_t bytes) {
     sl->keys_bytes = bytes;
     return JJS_OK;
 }
-// Large batches in the big slot only: the per-key tables are sized for n / KT_MIN_MULTIPLICITY keys per column.
+// Batches of at least this many items (big or medium slot): the per-key tables are sized for n / KT_MIN_MULTIPLICITY keys per column.
 constexpr size_t KT_MIN_ITEMS = 65536;
 bool key_path_applies(const verify_params& P) {
 #if defined(JJS_PROFILING)
     if (g_force_path == 3) return false;           // throughput path without the key tables
 #endif
-    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && sl == &g->slots[0] && P.n_eq >= 1;
+    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && P.n_eq >= 1;
 }
 // The compressed key columns of a wire call: launch_verify decodes them, once per key when the key tables engage and
 // once per item otherwise, into the affine columns the scheme descriptor already points at.
@@ -890,10 +898,11 @@ int init_device(device_state& d, int ordinal) {
     d.slots[0].grid_verify = prop.multiProcessorCount * per_cu_v;
     int lanes_blocks = d.slots[0].grid_verify > d.grid_sign ? d.slots[0].grid_verify : d.grid_sign;
     if (d.grid_msig > lanes_blocks) lanes_blocks = d.grid_msig;
-    for (int i = 0; i <= N_SMALL_SLOTS; ++i) {
+    for (int i = 0; i < N_SLOTS; ++i) {
         call_slot& c = d.slots[i];
-        if (i > 0) c.grid_verify = (int)(SMALL_SLOT_ITEMS / BLOCK);
-        const size_t lanes = i == 0 ? (size_t)lanes_blocks * BLOCK : SMALL_SLOT_ITEMS;
+        const size_t slot_items = i <= N_SMALL_SLOTS ? SMALL_SLOT_ITEMS : MEDIUM_SLOT_ITEMS;
+        if (i > 0) c.grid_verify = (int)(slot_items / BLOCK);
+        const size_t lanes = i == 0 ? (size_t)lanes_blocks * BLOCK : slot_items;
         HIP_TRY(hipMalloc(&c.workspace, lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
         HIP_TRY(hipEventCreateWithFlags(&c.last_use, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c.last_use, d.stream));

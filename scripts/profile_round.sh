@@ -24,6 +24,6 @@ timeout -k 10 200 python bench.py --ext --no-cpu-baseline > gpurun_out/bench_${T
 for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/phase_profile.py $s 20 2>/dev/null >> gpurun_out/phase_profile_${T}.jsonl; done
 timeout -k 10 200 python jubjub_schnorr_amd/tools/host_rate.py > gpurun_out/host_rate_${T}.json 2>/dev/null
 timeout -k 10 300 python jubjub_schnorr_amd/tools/multisig_rate.py > gpurun_out/multisig_rate_${T}.jsonl 2>/dev/null
-for s in single double; do timeout -k 10 200 python jubjub_schnorr_amd/tools/batch_size_curve.py $s > gpurun_out/batch_size_curve_${T}_$s.jsonl 2>/dev/null; done
+for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/batch_size_curve.py $s > gpurun_out/batch_size_curve_${T}_$s.jsonl 2>/dev/null; done
 bash scripts/clock_sample.sh $T
 cut -c1-200 gpurun_out/bench_${T}.json; tail -3 gpurun_out/pmc_${T}_single.log

@@ -678,6 +678,31 @@ def test_small_calls_on_different_streams_overlap_safely(eng):
         assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
 
 
+def test_medium_calls_with_key_tables_on_different_streams(eng):
+    """Calls of 65 536 ... 131 072 items take the medium slots in turn, each with its own workspace and key arena, and
+    share the device's key stream: five key-table calls (affine and wire inputs, all schemes) on five streams, more
+    streams than slots, two rounds; every status against the oracle."""
+    import torch
+    specs = [("single", 70000, False), ("double", 66000, False), ("vargen", 68000, True), ("single", 131072, True), ("double", 65536, True)]
+    batches = [make_batch(s, n, seed=1500 + i, n_keys=200) for i, (s, n, _) in enumerate(specs)]
+    args = []
+    for b, (s, _, wire) in zip(batches, specs):
+        args.append([dev(a) for a in to_wire(s, b)] if wire else [dev(b[k]) for k in ARG_ORDER[s]])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in specs]
+    outs = []
+    for _ in range(2):
+        outs = []
+        for a, (s, _, wire), stream in zip(args, specs, streams):
+            with torch.cuda.stream(stream):
+                outs.append(eng.verify_wire(s, *a) if wire else eng.verify(s, *a))
+    torch.cuda.synchronize()
+    for (st, tally), b, (s, _, _) in zip(outs, batches, specs):
+        want = oracle_verify(s, b)
+        assert (host(st) == want).all(), s
+        assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+
+
 def test_calls_on_different_streams_do_not_interfere(eng):
     """The engine's workspaces are shared; launches from different streams must be ordered by the library."""
     import torch
