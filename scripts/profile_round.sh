@@ -25,5 +25,8 @@ for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/to
 timeout -k 10 200 python jubjub_schnorr_amd/tools/host_rate.py > gpurun_out/host_rate_${T}.json 2>/dev/null
 timeout -k 10 300 python jubjub_schnorr_amd/tools/multisig_rate.py > gpurun_out/multisig_rate_${T}.jsonl 2>/dev/null
 for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/batch_size_curve.py $s > gpurun_out/batch_size_curve_${T}_$s.jsonl 2>/dev/null; done
+timeout -k 10 200 python jubjub_schnorr_amd/tools/kt_window_ab.py > gpurun_out/kt_window_ab_${T}.jsonl 2>/dev/null
+timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_${T}.jsonl 2>/dev/null
+GPU_MAX_HW_QUEUES=8 timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_8_hw_queues_${T}.jsonl 2>/dev/null
 bash scripts/clock_sample.sh $T
 cut -c1-200 gpurun_out/bench_${T}.json; tail -3 gpurun_out/pmc_${T}_single.log
