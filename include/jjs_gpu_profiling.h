@@ -27,6 +27,9 @@ int jjs_debug_force_path(int which);
  * devices (own stream, tables, workspace, staging each) that share the visible cards round-robin; the tallies are
  * then summed on the host, since two ranks on one card cannot form an RCCL clique. */
 int jjs_debug_allow_virtual_devices(int allow);
+/* Where the last host-buffer call on one device spent its host time: out[0] seconds copying the caller's arrays into
+ * the pinned slots, out[1] seconds waiting for a slot's previous upload, out[2] seconds in all, out[3] chunks. */
+int jjs_debug_host_timing(double out[4]);
 
 #ifdef __cplusplus
 }

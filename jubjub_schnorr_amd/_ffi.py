@@ -65,6 +65,7 @@ PROFILING_SIGNATURES = {
     "jjs_debug_skip_phases": [ctypes.c_uint],
     "jjs_debug_allow_virtual_devices": [_I],
     "jjs_debug_force_path": [_I],
+    "jjs_debug_host_timing": [_P],
 }
 _RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
 

@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -481,7 +483,11 @@ constexpr size_t SMALL_SLOT_ITEMS = 16384;
 // freely.  A medium slot has everything the big one has (workspace, key arena) for its size.
 constexpr int N_MEDIUM_SLOTS = 3;
 constexpr size_t MEDIUM_SLOT_ITEMS = 131072;
-constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS;
+// Larger calls take two big slots in turn: what two big batches in flight gain is each other's latency-bound stretches
+// (key dedup, the per-key doubling chains, the resolve pass), ~10 % of a batch, filled with the other's arithmetic.
+constexpr int N_BIG_SLOTS = 2;
+constexpr int SECOND_BIG_SLOT = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS;
+constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS + (N_BIG_SLOTS - 1);
 // largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
 // path is faster (tools/batch_size_curve.py)
 constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
@@ -492,9 +498,11 @@ constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARG
 
 struct device_state {
     int device = -1;               // HIP device ordinal
-    call_slot slots[N_SLOTS];          // [0] big, then the small ones, then the medium ones
-    unsigned next_small = 0, next_medium = 0;
+    call_slot slots[N_SLOTS];          // [0] big, then the small ones, then the medium ones, then the second big one
+    unsigned next_small = 0, next_medium = 0, next_big = 0;
     hipStream_t stream = nullptr;  // used by the host-buffer entry points
+    hipStream_t stream2 = nullptr; // ... whose chunks alternate between the two
+    hipEvent_t host_begin = nullptr;
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
     uint8_t* tag = nullptr;
@@ -579,6 +587,7 @@ uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_pr
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
 int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
+double g_host_timing[4] = {0, 0, 0, 0};   // last host-buffer call: seconds staging, waiting for slots, total; chunks
 int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
 #endif
 
@@ -586,7 +595,7 @@ int g_force_window = 0;           // ... 5: narrow windows on the key-table path
 void pick_slot(size_t n) {
     if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
     else if (n <= MEDIUM_SLOT_ITEMS) { sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium]; g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS; }
-    else sl = &g->slots[0];
+    else { sl = &g->slots[g->next_big ? SECOND_BIG_SLOT : 0]; g->next_big = (g->next_big + 1) % N_BIG_SLOTS; }
 }
 void big_slot() { sl = &g->slots[0]; }
 // Launches that use one slot are ordered one after the other on the device, also across streams: each waits
@@ -861,6 +870,8 @@ int init_device(device_state& d, int ordinal) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.host_begin, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
     {   // the per-key kernels are few, long waves that must finish before the challenge hashes do: dispatch them first
         int lo = 0, hi = 0;
@@ -900,9 +911,11 @@ int init_device(device_state& d, int ordinal) {
     if (d.grid_msig > lanes_blocks) lanes_blocks = d.grid_msig;
     for (int i = 0; i < N_SLOTS; ++i) {
         call_slot& c = d.slots[i];
+        const bool big = i == 0 || i == SECOND_BIG_SLOT;
         const size_t slot_items = i <= N_SMALL_SLOTS ? SMALL_SLOT_ITEMS : MEDIUM_SLOT_ITEMS;
-        if (i > 0) c.grid_verify = (int)(slot_items / BLOCK);
-        const size_t lanes = i == 0 ? (size_t)lanes_blocks * BLOCK : slot_items;
+        c.grid_verify = big ? d.slots[0].grid_verify : (int)(slot_items / BLOCK);
+        // slot 0 also serves the signer and the multisig kernels, whose grids may be larger than the verify grid
+        const size_t lanes = i == 0 ? (size_t)lanes_blocks * BLOCK : (big ? (size_t)c.grid_verify * BLOCK : slot_items);
         HIP_TRY(hipMalloc(&c.workspace, lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
         HIP_TRY(hipEventCreateWithFlags(&c.last_use, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c.last_use, d.stream));
@@ -946,6 +959,8 @@ void free_device(device_state& d) {
         if (d.chunk_done[i]) (void)hipEventDestroy(d.chunk_done[i]);
     }
     if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
+    if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
+    if (d.host_begin) (void)hipEventDestroy(d.host_begin);
     if (d.key_stream) { (void)hipStreamSynchronize(d.key_stream); (void)hipStreamDestroy(d.key_stream); }
     if (d.key_fork) (void)hipEventDestroy(d.key_fork);
     if (d.key_mid) (void)hipEventDestroy(d.key_mid);
@@ -1026,16 +1041,26 @@ struct device_restore {   // puts the calling thread back on the device it came 
 // Host-buffer calls.  The batch is cut into one contiguous block of ceil(n / devices) items per driven
 // device (the rule of jubjub_schnorr_amd/sharding.py) and every block is driven by its OWN host thread, so that
 // the uploads of different devices overlap (one thread issuing pageable copies for all devices would stage them
-// one after the other).  A block runs as a pipeline of chunks of at least HOST_CHUNK_ITEMS items: the thread copies
-// chunk c from the caller's (pageable) arrays into one of two pinned staging slots and queues its upload on the
-// device's copy stream while chunk c-1 is being verified on the compute stream and the statuses of chunk c-2
-// travel back into a pinned buffer.  Device arena, pinned staging and events are per device and only grow.  The
+// one after the other).  A block runs as a pipeline of chunks: the thread copies chunk c from the caller's (pageable)
+// arrays into one of two pinned staging slots -- with the help of a few more threads, a single one moves ~11 GB/s --
+// and queues its upload on the device's copy stream while chunk c-1 is being verified on the compute stream and the
+// statuses of chunk c-2 travel back into a pinned buffer.  The first chunk is small, because its upload is exposed;
+// every later one is HOST_CHUNK_GROWTH times its predecessor (the upload of a chunk takes about half as long per item
+// as the verification of the one before, and every chunk pays ~1 ms of its own), up to HOST_CHUNK_ITEMS_MAX.  Device arena, pinned staging and events are per device and only grow.  The
 // tallies accumulate over the chunks and are summed over the devices with one RCCL all-reduce at the end.
 // A failing block drains both of its streams before it reports, so nothing is in flight into the caller's or
 // the library's buffers when the call returns an error.
 struct host_col { const uint8_t* p; size_t width; };
-constexpr size_t HOST_CHUNK_ITEMS = size_t(1) << 18;
+#ifndef JJS_HOST_CHUNK_LOG2_FIRST        // build-time knobs of the A/B runs recorded in DESIGN.md 6
+#define JJS_HOST_CHUNK_LOG2_FIRST 16
+#define JJS_HOST_CHUNK_LOG2_MAX 19
+#define JJS_HOST_CHUNK_GROWTH 4
+#endif
+constexpr size_t HOST_CHUNK_ITEMS_FIRST = size_t(1) << JJS_HOST_CHUNK_LOG2_FIRST, HOST_CHUNK_ITEMS_MAX = size_t(1) << JJS_HOST_CHUNK_LOG2_MAX,
+                 HOST_CHUNK_GROWTH = JJS_HOST_CHUNK_GROWTH;
 constexpr size_t HOST_MAX_CHUNKS = 32;
+constexpr unsigned HOST_STAGING_THREADS_MAX = 8;
+constexpr size_t HOST_STAGING_MIN_BYTES = size_t(4) << 20;     // below this a chunk is copied by the calling thread alone
 
 bool g_keep_tally = false;   // set while run_host issues the chunks of one batch: the counters accumulate
 
@@ -1065,7 +1090,9 @@ size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
 
 template <size_t K>
 struct host_block {
-    size_t lo = 0, hi = 0, chunk = 0, chunks = 0;
+    size_t lo = 0, hi = 0, chunks = 0, largest = 0;
+    size_t start[HOST_MAX_CHUNKS + 1] = {};      // chunk c covers items [start[c], start[c + 1]) of the block
+    unsigned staging_threads = 1;
     int rc = JJS_OK;
     char err[512] = "";
     unsigned long long tally[4] = {0, 0, 0, 0};
@@ -1087,7 +1114,7 @@ int run_host_block(device_state* dev, const host_col (&cols)[K], host_block<K>& 
     for (size_t k = 0; k < K; ++k) { in[k] = p; p += pad256(nl * cols[k].width); }
     uint8_t* st = p;
     // pinned staging: two slots of one chunk of inputs each, then the statuses of the whole block
-    const size_t slot_bytes = pad256(b.chunk * row);
+    const size_t slot_bytes = pad256(b.largest * row);
     if (int rc = ensure_pinned(2 * slot_bytes + pad256(nl) + 256)) return rc;
     uint8_t* const slot[2] = {g->pinned, g->pinned + slot_bytes};
     uint8_t* const pst = g->pinned + 2 * slot_bytes;
@@ -1095,33 +1122,77 @@ int run_host_block(device_state* dev, const host_col (&cols)[K], host_block<K>& 
     HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
     HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
     HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
+    // successive chunks are verified on two streams in turn (and sit in different call slots), so that the
+    // latency-bound stretches of one chunk are filled with the arithmetic of the next
+    HIP_TRY(hipEventRecord(g->host_begin, g->stream));
+    HIP_TRY(hipStreamWaitEvent(g->stream2, g->host_begin, 0));
+    hipStream_t const compute[2] = {g->stream, g->stream2};
+#if defined(JJS_PROFILING)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_stage = 0, t_wait = 0;
+#endif
     for (size_t c = 0; c <= b.chunks; ++c) {
         if (c < b.chunks) {
-            const size_t off = c * b.chunk, len = (off + b.chunk < nl) ? b.chunk : (nl - off);
+            const size_t off = b.start[c], len = b.start[c + 1] - off;
+#if defined(JJS_PROFILING)
+            const double t0 = now();
+#endif
             if (c >= 2) HIP_TRY(hipEventSynchronize(g->chunk_up[c - 2]));      // the slot's previous upload has left it
+#if defined(JJS_PROFILING)
+            const double t1 = now();
+            t_wait += t1 - t0;
+#endif
             const void* dp[K];
             uint8_t* hp = slot[c & 1];
+            // pageable -> pinned: thread t of T copies the t-th slice of every column
+            const unsigned T = len * row >= HOST_STAGING_MIN_BYTES ? b.staging_threads : 1u;
+            auto stage = [&](unsigned t) {
+                const size_t i0 = len * t / T, i1 = len * (t + 1) / T;
+                uint8_t* q = hp;
+                for (size_t k = 0; k < K; ++k) {
+                    const size_t w = cols[k].width;
+                    memcpy(q + i0 * w, cols[k].p + (b.lo + off + i0) * w, (i1 - i0) * w);
+                    q += len * w;
+                }
+            };
+            {
+                std::vector<std::thread> helpers;
+                for (unsigned t = 1; t < T; ++t) helpers.emplace_back(stage, t);
+                stage(0);
+                for (std::thread& h : helpers) h.join();
+            }
+#if defined(JJS_PROFILING)
+            t_stage += now() - t1;
+#endif
             for (size_t k = 0; k < K; ++k) {
                 const size_t w = cols[k].width;
-                memcpy(hp, cols[k].p + (b.lo + off) * w, len * w);
                 HIP_TRY(hipMemcpyAsync(in[k] + off * w, hp, len * w, hipMemcpyHostToDevice, g->copy_stream));
                 dp[k] = in[k] + off * w;
                 hp += len * w;
             }
             HIP_TRY(hipEventRecord(g->chunk_up[c], g->copy_stream));
-            HIP_TRY(hipStreamWaitEvent(g->stream, g->chunk_up[c], 0));
-            if (int rc = launch(dp, len, (void*)(st + off), (void*)g->tally, (void*)g->stream)) return rc;
-            HIP_TRY(hipEventRecord(g->chunk_done[c], g->stream));
+            HIP_TRY(hipStreamWaitEvent(compute[c & 1], g->chunk_up[c], 0));
+            if (int rc = launch(dp, len, (void*)(st + off), (void*)g->tally, (void*)compute[c & 1])) return rc;
+            HIP_TRY(hipEventRecord(g->chunk_done[c], compute[c & 1]));
         }
         if (c > 0 && status) {            // statuses of the previous chunk, behind this chunk's upload
-            const size_t off = (c - 1) * b.chunk, len = (off + b.chunk < nl) ? b.chunk : (nl - off);
+            const size_t off = b.start[c - 1], len = b.start[c] - off;
             HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->chunk_done[c - 1], 0));
             HIP_TRY(hipMemcpyAsync(pst + off, st + off, len, hipMemcpyDeviceToHost, g->copy_stream));
         }
     }
+    // the second stream joins the first: what follows on g->stream (tally all-reduce, download) sees every chunk
+    if (b.chunks) {
+        HIP_TRY(hipEventRecord(g->host_begin, g->stream2));
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->host_begin, 0));
+    }
     HIP_TRY(hipStreamSynchronize(g->stream));
     HIP_TRY(hipStreamSynchronize(g->copy_stream));
     if (status && nl) memcpy(status + b.lo, pst, nl);
+#if defined(JJS_PROFILING)
+    g_host_timing[0] = t_stage; g_host_timing[1] = t_wait; g_host_timing[2] = now() - t_begin; g_host_timing[3] = (double)b.chunks;
+#endif
     return JJS_OK;
 }
 
@@ -1136,15 +1207,37 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
     device_restore restore;
     struct keep_tally_scope { keep_tally_scope() { g_keep_tally = true; } ~keep_tally_scope() { g_keep_tally = false; } } keep;
     const size_t per = (n + nd - 1) / nd;
+    // staging helpers: the host cores this process may use, shared among the devices it drives
+    unsigned staging_threads = 1;
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const unsigned cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : 1u;
+        staging_threads = cores / (unsigned)nd;
+        if (staging_threads > HOST_STAGING_THREADS_MAX) staging_threads = HOST_STAGING_THREADS_MAX;
+        if (staging_threads < 1) staging_threads = 1;
+    }
     for (size_t d = 0; d < nd; ++d) {
         host_block<K>& b = blocks[d];
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
         const size_t nl = b.hi - b.lo;
-        b.chunk = HOST_CHUNK_ITEMS;
-        if (nl > b.chunk * HOST_MAX_CHUNKS) b.chunk = ((nl + HOST_MAX_CHUNKS - 1) / HOST_MAX_CHUNKS + 255) & ~size_t(255);
-        if (nl < b.chunk) b.chunk = nl ? nl : 1;                  // small calls pin only what they use
-        b.chunks = (nl + b.chunk - 1) / b.chunk;
+        // chunk sizes: FIRST, then times GROWTH up to MAX (raised when the block would need more than HOST_MAX_CHUNKS);
+        // a remainder of less than half a first chunk joins the chunk before it; small calls pin only what they use
+        size_t cap = HOST_CHUNK_ITEMS_MAX;
+        if (nl > cap * (HOST_MAX_CHUNKS - 4)) cap = ((nl + HOST_MAX_CHUNKS - 5) / (HOST_MAX_CHUNKS - 4) + 255) & ~size_t(255);
+        size_t pos = 0, next = HOST_CHUNK_ITEMS_FIRST;
+        b.chunks = 0; b.largest = 1;
+        while (pos < nl) {
+            size_t len = next < nl - pos ? next : nl - pos;
+            if (nl - pos - len < HOST_CHUNK_ITEMS_FIRST / 2) len = nl - pos;
+            b.start[b.chunks++] = pos;
+            pos += len;
+            if (len > b.largest) b.largest = len;
+            next = next * HOST_CHUNK_GROWTH < cap ? next * HOST_CHUNK_GROWTH : cap;
+        }
+        b.start[b.chunks] = nl;
+        b.staging_threads = staging_threads;
     }
     auto work = [&](size_t d) {
         host_block<K>& b = blocks[d];
@@ -1152,6 +1245,7 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
         if (b.rc != JJS_OK) {
             // leave nothing in flight into the caller's arrays, the pinned slots or the counters
             (void)hipStreamSynchronize(targets[d]->stream);
+            (void)hipStreamSynchronize(targets[d]->stream2);
             (void)hipStreamSynchronize(targets[d]->copy_stream);
             snprintf(b.err, sizeof(b.err), "%s", t_err);
         }
@@ -1814,6 +1908,11 @@ int jjs_debug_force_path(int which) {
     g_force_path = which & 3;                       // 0 by size and keys, 1 throughput (key tables allowed), 2 latency, 3 throughput without key tables
     g_force_positions = ((which >> 4) & 15) == 4 || ((which >> 4) & 15) == 8 ? ((which >> 4) & 15) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
     g_force_window = (which >> 8) == KT_WINDOW_NARROW ? (which >> 8) : 0;   // 0x500: narrow key-table windows whatever the keys
+    return JJS_OK;
+}
+int jjs_debug_host_timing(double out[4]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    for (int i = 0; i < 4; ++i) out[i] = g_host_timing[i];
     return JJS_OK;
 }
 int jjs_debug_allow_virtual_devices(int allow) {

@@ -45,7 +45,7 @@ def test_product_library_has_no_bypass_switch():
     the -DJJS_PROFILING build, which declares them in include/jjs_gpu_profiling.h."""
     from jubjub_schnorr_amd import _ffi
     prof_syms = header_symbols("jjs_gpu_profiling.h")
-    assert prof_syms == ["jjs_debug_allow_virtual_devices", "jjs_debug_force_path", "jjs_debug_skip_phases"] == sorted(_ffi.PROFILING_SIGNATURES)
+    assert prof_syms == ["jjs_debug_allow_virtual_devices", "jjs_debug_force_path", "jjs_debug_host_timing", "jjs_debug_skip_phases"] == sorted(_ffi.PROFILING_SIGNATURES)
     product = exported(os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so"))
     for s in prof_syms:
         assert s not in product, s
