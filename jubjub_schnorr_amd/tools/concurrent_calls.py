@@ -18,8 +18,8 @@ def main():
     eng = jjs.engine()
     arrays, expect = bench.make_inputs(eng, "single", 1 << 20, 0)
     streams = [torch.cuda.Stream() for _ in range(6)]
-    for n in (1024, 4096, 16384, 32768, 65536, 131072):
-        calls = 12
+    for n in (1024, 4096, 16384, 32768, 65536, 131072, 262144, 1048576):
+        calls = 12 if n <= 131072 else 6
         batches = [[arrays[k][i * n:(i + 1) * n].contiguous() for k in bench.ARG_ORDER["single"]] for i in range(min(calls, (1 << 20) // n))]
         for k in (1, 2, 3, 6):
             def issue():

@@ -680,27 +680,26 @@ def test_small_calls_on_different_streams_overlap_safely(eng):
 
 def test_medium_calls_with_key_tables_on_different_streams(eng):
     """Calls of 65 536 ... 131 072 items take the medium slots in turn, each with its own workspace and key arena, and
-    share the device's key stream: five key-table calls (affine and wire inputs, all schemes) on five streams, more
-    streams than slots, two rounds; every status against the oracle."""
+    share the device's key stream: five key-table calls (one batch per scheme; affine and wire entry points) on five
+    streams, more streams than slots, two rounds; every status against the oracle."""
     import torch
-    specs = [("single", 70000, False), ("double", 66000, False), ("vargen", 68000, True), ("single", 131072, True), ("double", 65536, True)]
-    batches = [make_batch(s, n, seed=1500 + i, n_keys=200) for i, (s, n, _) in enumerate(specs)]
-    args = []
-    for b, (s, _, wire) in zip(batches, specs):
-        args.append([dev(a) for a in to_wire(s, b)] if wire else [dev(b[k]) for k in ARG_ORDER[s]])
+    batches = {"single": make_batch("single", 70000, seed=1500, n_keys=200), "double": make_batch("double", 66000, seed=1501, n_keys=200),
+               "vargen": make_batch("vargen", 68000, seed=1502, n_keys=200)}
+    want = {s: oracle_verify(s, b) for s, b in batches.items()}
+    specs = [("single", False), ("double", False), ("vargen", True), ("single", True), ("double", True)]
+    args = [[dev(a) for a in to_wire(s, batches[s])] if wire else [dev(batches[s][k]) for k in ARG_ORDER[s]] for s, wire in specs]
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in specs]
     outs = []
     for _ in range(2):
         outs = []
-        for a, (s, _, wire), stream in zip(args, specs, streams):
+        for a, (s, wire), stream in zip(args, specs, streams):
             with torch.cuda.stream(stream):
                 outs.append(eng.verify_wire(s, *a) if wire else eng.verify(s, *a))
     torch.cuda.synchronize()
-    for (st, tally), b, (s, _, _) in zip(outs, batches, specs):
-        want = oracle_verify(s, b)
-        assert (host(st) == want).all(), s
-        assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+    for (st, tally), (s, _) in zip(outs, specs):
+        assert (host(st) == want[s]).all(), s
+        assert host(tally).tolist() == [int((want[s] == k).sum()) for k in range(4)]
 
 
 def test_calls_on_different_streams_do_not_interfere(eng):
