@@ -368,8 +368,8 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scheme", default="all", choices=["all", "single", "double", "vargen"],
                     help="all (default): headline = single, plus double and vargen in `schemes`")
     ap.add_argument("--log2-items-per-gpu", type=int, default=None,
