@@ -475,6 +475,7 @@ struct call_slot {
     uint8_t* keys = nullptr;          // key-table path: hash tables, key ids, bases and window tables per key (grow-only)
     size_t keys_bytes = 0;
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
+    hipStream_t last_stream = nullptr;// ... and the stream it was issued on
 };
 constexpr int N_SMALL_SLOTS = 3;
 constexpr size_t SMALL_SLOT_ITEMS = 16384;
@@ -592,12 +593,20 @@ int g_force_window = 0;           // ... 5: narrow windows on the key-table path
 #endif
 
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
-void pick_slot(size_t n) {
+void pick_slot(size_t n, hipStream_t s) {
     if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
     else if (n <= MEDIUM_SLOT_ITEMS) { sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium]; g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS; }
-    else { sl = &g->slots[g->next_big ? SECOND_BIG_SLOT : 0]; g->next_big = (g->next_big + 1) % N_BIG_SLOTS; }
+    else {
+        // a big slot is a big arena: calls that follow each other on one stream are ordered anyway and stay in one
+        // slot; a call from another stream takes the other one if this one is still busy
+        call_slot &a = g->slots[0], &b = g->slots[SECOND_BIG_SLOT];
+        if (a.last_stream == s) sl = &a;
+        else if (b.last_stream == s) sl = &b;
+        else sl = hipEventQuery(a.last_use) == hipSuccess ? &a : (hipEventQuery(b.last_use) == hipSuccess ? &b : (g->next_big++ % N_BIG_SLOTS ? &b : &a));
+    }
+    sl->last_stream = s;
 }
-void big_slot() { sl = &g->slots[0]; }
+void big_slot() { sl = &g->slots[0]; sl->last_stream = nullptr; }
 // Launches that use one slot are ordered one after the other on the device, also across streams: each waits
 // for the slot's previous user.
 int begin_shared(hipStream_t s) {
@@ -1353,7 +1362,7 @@ int jjs_stream_sync(void* stream) {
 static int affine_single_locked(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
                                 void* stream) {
     if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
                                            g->comb_g, o), status, tally, (hipStream_t)stream);
@@ -1361,7 +1370,7 @@ static int affine_single_locked(const void* u, const void* R, const void* PK, co
 static int affine_double_locked(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
                                 size_t n, void* status, void* tally, void* stream) {
     if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
                                            (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o),
@@ -1370,7 +1379,7 @@ static int affine_double_locked(const void* u, const void* R, const void* Rp, co
 static int affine_vargen_locked(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
                                 void* status, void* tally, void* stream) {
     if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
     return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
                                            (const uint8_t*)m, n, o), status, tally, (hipStream_t)stream);
@@ -1453,7 +1462,7 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -1476,7 +1485,7 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -1502,7 +1511,7 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
@@ -1576,7 +1585,7 @@ static int ext_single_locked(const void* u, const void* R, const void* PK, const
     if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
@@ -1595,7 +1604,7 @@ static int ext_double_locked(const void* u, const void* R, const void* Rp, const
     if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
@@ -1617,7 +1626,7 @@ static int ext_vargen_locked(const void* u, const void* R, const void* PK, const
     if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n);
+    pick_slot(n, (hipStream_t)stream);
     if (int rc = ensure_wire(n)) return rc;
     if (int rc = begin_shared(s)) return rc;
     normalize_params N{};
