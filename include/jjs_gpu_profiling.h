@@ -21,7 +21,8 @@ int jjs_debug_skip_phases(unsigned mask);
  * 1 = never the latency path, 3 = never the latency path and never the key tables (every key a fresh variable
  * point), 2 = the latency path for every single / double call of at most 16 384 items; 0x42 / 0x82 = the
  * latency path with the scalars cut into 4 / 8 pieces whatever the size; 0x500 = 5-bit windows whenever the key
- * tables engage (the product takes 6-bit windows from 128 signatures per key). */
+ * tables engage (the product takes 6-bit windows from 128 signatures per key); 0x1000 = the key-table path takes the
+ * items in the caller's order instead of grouping them by key. */
 int jjs_debug_force_path(int which);
 /* Test mode for boxes with one GPU: a later jjs_init(k) with k above the visible device count creates k logical
  * devices (own stream, tables, workspace, staging each) that share the visible cards round-robin; the tallies are

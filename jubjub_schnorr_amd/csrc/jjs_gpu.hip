@@ -169,14 +169,44 @@ __global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {
     const uint32_t c = (uint32_t)(t / per_col), id = (uint32_t)((t % per_col) / positions), pos = (uint32_t)(t % positions);
     if (c < K.n_cols && id < K.counters[c]) kt_table_lane(kt_col(K, (int32_t)c), id, pos, w);
 }
+// Items grouped by key (column 0): histogram, exclusive scan, scatter.  All three leave at once when the batch does not
+// take the key-table path.
+__global__ __launch_bounds__(BLOCK) void key_count_kernel(key_params K) {
+    if (!K.counters[2]) return;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) atomicAdd(&K.key_cursor[K.col[0].keyid[item]], 1u);
+}
+__global__ __launch_bounds__(1024) void key_scan_kernel(key_params K) {          // one block
+    if (!K.counters[2]) return;
+    __shared__ uint32_t part[1024];
+    const uint32_t keys = K.counters[0], per = (keys + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < keys ? lo + per : keys;
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += K.key_cursor[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;                 // exclusive prefix of this thread's keys
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = K.key_cursor[k]; K.key_cursor[k] = run; run += c; }
+}
+__global__ __launch_bounds__(BLOCK) void key_scatter_kernel(key_params K) {
+    if (!K.counters[2]) return;
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
+        K.order[K.keep_order ? (uint32_t)item : atomicAdd(&K.key_cursor[K.col[0].keyid[item]], 1u)] = (uint32_t)item;
+}
 __global__ __launch_bounds__(BLOCK, 2) void key_verify_kernel(verify_params P, key_params K) {
     if (!keyed_mode(P)) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t base = 0; base < P.n; base += total) {
-        const uint64_t item = base + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-        const bool active = item < P.n;
-        const uint64_t it = active ? item : P.n - 1;
-        publish_status(P, item, active, kt_finish_item(P, K, it, load_prep(P.prep, P.n, it)));
+        const uint64_t idx = base + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        const bool active = idx < P.n;
+        const uint64_t item = K.order[active ? idx : P.n - 1];
+        publish_status(P, item, active, kt_finish_item(P, K, item, load_prep(P.prep, P.n, item)));
     }
 }
 
@@ -589,6 +619,7 @@ bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (lib
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
 int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
 double g_host_timing[4] = {0, 0, 0, 0};   // last host-buffer call: seconds staging, waiting for slots, total; chunks
+bool g_keep_order = false;        // ... 0x1000: key-table path without grouping the items by key
 int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
 #endif
 
@@ -716,6 +747,7 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     K.max_keys = (uint32_t)(P.n / KT_MIN_MULTIPLICITY);
 #if defined(JJS_PROFILING)
     K.force_window = (uint32_t)g_force_window;
+    K.keep_order = g_keep_order ? 1u : 0u;
 #endif
     // key columns: PK of every equation, and the generator where it is per-item data
     fe_src cols[2];
@@ -730,10 +762,14 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + 2 * pad(K.max_keys) +
                            pad(kt_base_words_for(P.n) * 4) + pad(kt_table_words_for(P.n) * 4);
-    if (int rc = ensure_keys(256 + n_cols * per_col)) return rc;
+    const size_t order_bytes = pad(P.n * 4) + pad(((size_t)K.max_keys + 1) * 4);
+    if (int rc = ensure_keys(256 + order_bytes + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
     HIP_TRY(hipMemsetAsync(K.counters, 0, 256, s));
+    K.order = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
+    K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad(((size_t)K.max_keys + 1) * 4);
+    HIP_TRY(hipMemsetAsync(K.key_cursor, 0, ((size_t)K.max_keys + 1) * 4, s));
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
         C.src = cols[c];
@@ -831,6 +867,9 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
             HIP_TRY(hipStreamWaitEvent(s, g->key_mid, 0));
             hipLaunchKernelGGL(key_unpack_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd, D);
         }
+        hipLaunchKernelGGL(key_count_kernel, dim3(item_blocks), dim3(BLOCK), 0, g->key_stream, K);
+        hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(1024), 0, g->key_stream, K);
+        hipLaunchKernelGGL(key_scatter_kernel, dim3(item_blocks), dim3(BLOCK), 0, g->key_stream, K);
         hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, K);
         hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
                            dim3(BLOCK), 0, g->key_stream, K);
@@ -1916,7 +1955,8 @@ int jjs_debug_force_path(int which) {
     std::lock_guard<std::mutex> lock(L.mu);
     g_force_path = which & 3;                       // 0 by size and keys, 1 throughput (key tables allowed), 2 latency, 3 throughput without key tables
     g_force_positions = ((which >> 4) & 15) == 4 || ((which >> 4) & 15) == 8 ? ((which >> 4) & 15) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
-    g_force_window = (which >> 8) == KT_WINDOW_NARROW ? (which >> 8) : 0;   // 0x500: narrow key-table windows whatever the keys
+    g_keep_order = (which & 0x1000) != 0;
+    g_force_window = ((which >> 8) & 15) == KT_WINDOW_NARROW ? ((which >> 8) & 15) : 0;   // 0x500: narrow key-table windows whatever the keys
     return JJS_OK;
 }
 int jjs_debug_host_timing(double out[4]) {

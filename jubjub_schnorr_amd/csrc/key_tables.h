@@ -81,7 +81,12 @@ struct key_params {
     uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 0 = throughput path, else the window width of
                              // the key-table path; [3] a probe sequence overflowed
     uint32_t force_window;   // profiling build only (0 in the product): KT_WINDOW_NARROW = never the wide windows
+    uint32_t keep_order;     // profiling build only (0 in the product): the lanes take the items in the caller's order
     uint64_t n;
+    // the items grouped by their key of column 0 (counting sort on the device): lane i of key_verify_kernel takes item
+    // order[i], so the lanes of a wave look up the tables of one or two keys instead of 64
+    uint32_t* order;         // [n]
+    uint32_t* key_cursor;    // [max_keys + 1] items per key, then start of each key's run (advanced while scattering)
 };
 
 // column `idx` (0 or 1) of K, chosen field by field: indexing the kernel-argument struct with a run-time index
