@@ -14,8 +14,9 @@ extern "C" {
 #endif
 
 /* Ablations (results become meaningless): skip phases of the verify kernels in later launches; bit0 = point
- * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars), bit4 = every window / comb /
- * key-table lookup reads from a cache-resident subset of its table (what the gathers cost); 0 restores the full path. */
+ * validity, bit1 = challenge hash, bit2 = equations, bit3 = Euclid (stand-in scalars), bit4 = every window / comb
+ * lookup of the throughput path, and every comb lookup of the key-table path, reads from a cache-resident subset of
+ * its table (what the gathers cost); 0 restores the full path. */
 int jjs_debug_skip_phases(unsigned mask);
 /* Path selection for A/B timing (results stay exact): 0 = by batch size and key repetition (product behaviour),
  * 1 = never the latency path, 3 = never the latency path and never the key tables (every key a fresh variable

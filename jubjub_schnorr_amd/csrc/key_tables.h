@@ -263,12 +263,12 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
             const uint32_t id = C.keyid[item], f = C.key_flags[id];
             keys_valid = keys_valid && (f & KT_KEY_VALID) != 0;
             keys_malformed = keys_malformed || (f & KT_KEY_MALFORMED) != 0;
-            // JJS_SKIP bit 4 (profiling build only, constant false in the product): the lanes share 64 keys' tables
-            // (8 MB, cache-resident, no hot spot) -- what the gathers cost
-            acc = kt_add_scalar(acc, C, JJS_SKIP(P, 16u) ? (id & 63u) : id, r.c, w);     // c * PK
+            acc = kt_add_scalar(acc, C, id, r.c, w);                          // c * PK
         }
         if (E.comb) {
-            acc = add_comb(acc, E.comb, u);                                   // + u * G (G')
+            // JJS_SKIP bit 4 (profiling build only, constant false in the product): 256 entries per comb row, a
+            // cache-resident working set -- what the comb gathers cost
+            acc = add_comb(acc, E.comb, u, JJS_SKIP(P, 16u));                 // + u * G (G')
         } else {
             const key_column C = kt_col(K, E.gen_col);
             const uint32_t id = C.keyid[item], f = C.key_flags[id];
@@ -281,6 +281,7 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
     }
     if (r.malformed || keys_malformed) return ST_MALFORMED;
     if (!r.valid || !keys_valid) return ST_INVALID_POINT;
+    if (JJS_SKIP(P, 1u)) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;        // profiling only: no resolve pass
     // the equations hold: every R is a sum of torsion-free points; they fail: R's own subgroup test decides
     return eq_ok ? ST_OK : ST_PENDING_EQ_FAILED;
 }

@@ -51,11 +51,17 @@ def main():
     # so that no item goes through the resolve pass)
     out["ms_without_validity_lookups_cache_resident"] = timed(1 | 16)
     out["ms_gathers"] = out["ms_without_validity"] - out["ms_without_validity_lookups_cache_resident"]
-    # the same question for the key-table path (its tables: ~1 GB for the 8 k keys of this batch): every lane on key 0
+    # the key-table path: the product groups the items by key, so that a wave looks up one or two keys' tables;
+    # 0x1000 keeps the caller's order (64 keys per wave, ~1 GB of tables touched at random); bit 4 there confines the
+    # comb lookups to 256 entries per row (point checks off in both runs: no resolve pass)
     _ffi.check(_ffi.lib().jjs_debug_force_path(1), "force_path")
     out["ms_key_table_path"] = timed(0)
-    out["ms_key_table_path_lanes_on_64_keys"] = timed(16)
-    out["ms_key_table_gathers"] = out["ms_key_table_path"] - out["ms_key_table_path_lanes_on_64_keys"]
+    out["ms_key_table_path_no_validity"] = timed(1)
+    out["ms_key_table_path_no_validity_comb_cache_resident"] = timed(1 | 16)
+    out["ms_key_table_comb_gathers"] = out["ms_key_table_path_no_validity"] - out["ms_key_table_path_no_validity_comb_cache_resident"]
+    _ffi.check(_ffi.lib().jjs_debug_force_path(1 | 0x1000), "force_path")
+    out["ms_key_table_path_callers_order"] = timed(0)
+    out["ms_key_table_grouping_gain"] = out["ms_key_table_path_callers_order"] - out["ms_key_table_path"]
     _ffi.lib().jjs_debug_force_path(0)
     _ffi.lib().jjs_debug_skip_phases(0)
     print(json.dumps(out))
