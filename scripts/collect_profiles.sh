@@ -1,11 +1,38 @@
 #!/bin/bash
-# Copy what scripts/profile_round.sh <tag> left in gpurun_out/ into profiles/ (the tracked, judged copies).
-T=${1:?tag}
-cd "$(dirname "$0")/.."
-python jubjub_schnorr_amd/tools/pmc_summary.py $T "${2:-$T}" gpurun_out/prof_${T}_trace gpurun_out/prof_${T}_fetch gpurun_out/prof_${T}_write gpurun_out/prof_${T}_sq > /dev/null
-cp gpurun_out/${T}_kernel_stats.csv profiles/${T}_kernel_stats.csv
-for s in single double vargen; do cp gpurun_out/bench_${T}_$s.json profiles/${T}_bench_$s.json; cp gpurun_out/bench_${T}_${s}_wire.json profiles/${T}_bench_${s}_wire.json; done
-cp gpurun_out/phase_profile_${T}.jsonl profiles/${T}_phase_profile.jsonl
-cp gpurun_out/host_rate_${T}.json profiles/${T}_host_buffer_rate.json
-cp gpurun_out/multisig_rate_${T}.jsonl profiles/${T}_multisig_rate.jsonl
-ls profiles | grep "^${T}_"
+# Copies the summaries of one profiling pass (scripts/profile_round.sh <tag>, merged back under gpurun_out/) into
+# profiles/.  Usage: bash scripts/collect_profiles.sh <tag>
+T=${1:?tag}; cd "$(dirname "$0")/.."
+cp gpurun_out/pmc_latest.json gpurun_out/${T}_pmc_summary*.json profiles/
+cp gpurun_out/bench_$T.json profiles/${T}_bench.json
+cp gpurun_out/bench_${T}_wire.json profiles/${T}_bench_wire.json
+cp gpurun_out/bench_${T}_ext.json profiles/${T}_bench_ext.json
+for s in single double vargen single_unique; do cp gpurun_out/${T}_kernel_stats_$s.csv profiles/; done
+cp gpurun_out/phase_profile_$T.jsonl profiles/${T}_phase_profile.jsonl
+cp gpurun_out/host_rate_$T.json profiles/${T}_host_buffer_rate.json
+cp gpurun_out/multisig_rate_$T.jsonl profiles/${T}_multisig_rate.jsonl
+for s in single double vargen; do cp gpurun_out/batch_size_curve_${T}_$s.jsonl profiles/${T}_batch_size_curve_$s.jsonl; done
+cp gpurun_out/clock_power_$T.jsonl profiles/${T}_clock_power.jsonl
+cp gpurun_out/clock_power_${T}_bench.json profiles/${T}_clock_power_bench.json
+cp gpurun_out/kt_window_ab_$T.jsonl profiles/${T}_kt_window_ab.jsonl
+cp gpurun_out/concurrent_calls_$T.jsonl profiles/${T}_concurrent_calls.jsonl
+cp gpurun_out/concurrent_calls_8_hw_queues_$T.jsonl profiles/${T}_concurrent_calls_8_hw_queues.jsonl
+python3 - "$T" <<'PY'
+import json, sys
+sys.path.insert(0, "."); import bench
+T = sys.argv[1]
+print("pmc hash matches csrc:", json.load(open("profiles/pmc_latest.json"))["csrc_sha256"] == bench.csrc_hash())
+d = json.load(open(f"profiles/{T}_bench.json"))
+print("single", d["value"], d["ms_per_step"], "traffic", d["roofline"]["traffic"], "alu", d["alu_roofline"] and (d["alu_roofline"]["frac"], d["alu_roofline"]["valu_wave_instr_per_64_verifies"]))
+print("two streams", d.get("pipelined_two_streams"))
+for k, v in d["schemes"].items():
+    print(k, v["value"], v["ms_per_step"], v["roofline"]["traffic"], v["alu_roofline"] and v["alu_roofline"]["frac"], v["cpu_baseline"]["value"], v["cpu_baseline"]["one_thread"]["value"])
+print("unique", d["unique_keys"]["value"], d["unique_keys"]["ms_per_step"])
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["one_thread"]["value"])
+for f in (f"{T}_bench_wire.json", f"{T}_bench_ext.json"):
+    w = json.load(open("profiles/" + f)); print(f, w["value"], {k: v["value"] for k, v in w.get("schemes", {}).items()})
+print(open(f"profiles/{T}_host_buffer_rate.json").read())
+rows = [json.loads(l) for l in open(f"profiles/{T}_clock_power.jsonl")]
+sc = sorted(int(r["rocm_smi"]["card0"]["sclk clock speed:"].strip("()Mhz")) for r in rows); pw = sorted(float(r["rocm_smi"]["card0"]["Current Socket Graphics Package Power (W)"]) for r in rows)
+print("sclk", sc[2], sc[len(sc) // 2], sc[-3], "power", pw[3], pw[len(pw) // 2], pw[-1])
+b = json.load(open(f"profiles/{T}_clock_power_bench.json")); print("long run", b["value"], b["ms_per_step"], b["steps"])
+PY
