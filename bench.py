@@ -359,7 +359,7 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
                              "traffic / alu_roofline are null unless profiles/pmc_latest.json was measured on this csrc hash"},
         "alu_roofline": alu,
     }
-    if world == 1 and not (args.wire or args.ext) and scheme == "single" and n_keys == N_KEYS:
+    if world == 1 and not (args.wire or args.ext or args.no_two_streams) and scheme == "single" and n_keys == N_KEYS:
         # Secondary figure, never `value`: the same K batches issued on two streams in turn.  Two big calls in flight
         # sit in two call slots and fill each other's latency-bound stretches (key dedup, per-key chains, resolve pass).
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -395,6 +395,8 @@ def main():
     ap.add_argument("--log2-items-per-gpu", type=int, default=None,
                     help="override the BASELINE sizes (2^20 per GPU; 2^21 for single at --gpus 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-streams", action="store_true",
+                    help="skip the secondary two-stream figure (profiling passes: overlapping kernels would blur per-kernel times)")
     ap.add_argument("--wire", action="store_true",
                     help="feed the reference's wire formats (compressed points, decoded on the device)")
     ap.add_argument("--ext", action="store_true",
