@@ -42,12 +42,13 @@
  *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
  * thread and are serialised by one internal mutex (jjs_stream_sync only reads state under it and waits
- * outside).  The *_dev calls are asynchronous.  Calls of more than 16 384 items share the engine's big workspace
- * and are ordered on the device (each waits for the previous one, also across streams); smaller calls take one of
- * three small slots in turn, so small batches issued on different streams overlap on the device.
+ * outside).  The *_dev calls are asynchronous.  A call takes one of the engine's call slots by size (three for calls of
+ * at most 16 384 items, three for at most 131 072, two for larger ones): calls in different slots share no buffer and
+ * overlap on the device when they are issued on different streams; calls in one slot are ordered on the device (each
+ * waits for the previous one, also across streams).
  *
  * Method: the engine picks, per call, from the batch size and the repetition of its keys alone (no configuration):
- * at most 16 384 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
+ * at most 32 768 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
  * ~0.85 ms var-generator up to 4 096 items); larger -> one signature per lane; at least 65 536 items whose public
  * keys (and per-item generators) repeat 16 times or more on average -> per-key tables built inside the call.  The
  * status bytes are the same on every path.

@@ -9,7 +9,7 @@
 //   key tables  (key_tables.h)    >= 65 536 items whose keys repeat >= 16 times on average: keys deduplicated on the
 //               device, validity and window tables once per key (second stream, beside the hashes), additions only
 //               per signature (key_verify_kernel); decided on the device, no host round trip;
-//   latency     (small_batch.h)   <= 16 384 items: one signature spread over 11-45 lanes in two launches.
+//   latency     (small_batch.h)   <= 32 768 items: one signature spread over 11-45 lanes in two launches.
 // The per-status tally is reduced with wave ballots and one atomic per wave per status.  One process can drive
 // several devices (jjs_init); all state is per device, per-call state lives in call slots (call_slot).
 #include <hip/hip_runtime.h>
@@ -44,10 +44,14 @@ constexpr int BLOCK = 256;
 
 // First kernel of a batch: everything that does not need the window tables (see prepare_item).  No
 // per-lane workspace, about half the registers of verify_kernel: four waves per SIMD.
-__global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P) {
+// phase: PREP_ALL, or PREP_HEAD / PREP_TAIL for a batch whose keys are still being counted when the launch starts
+// (verify_core.h prep_phase); the tail leaves at once when the key tables engaged.
+__global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P, int phase) {
+    if (phase == PREP_TAIL && keyed_mode(P)) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total)
-        store_prep(P.prep, P.n, item, prepare_item(P, item));
+        store_prep(P.prep, P.n, item, phase == PREP_TAIL ? prepare_tail(P, item, load_prep(P.prep, P.n, item))
+                                                         : prepare_item(P, item, true, -1, (prep_phase)phase));
 }
 
 // What a first-pass lane does with its verdict: final statuses go to the caller's array and the tally (wave
@@ -521,11 +525,11 @@ constexpr int SECOND_BIG_SLOT = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS;
 constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS + (N_BIG_SLOTS - 1);
 // largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
 // path is faster (tools/batch_size_curve.py)
-constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
+constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 32768, 32768};
 // up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
-constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
+constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 32768, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
 struct device_state {
     int device = -1;               // HIP device ordinal
@@ -795,7 +799,7 @@ bool small_path_applies(const verify_params& P) {
         if (!P.eq[k].comb) return false;
 #if defined(JJS_PROFILING)
     if (g_force_path == 1 || g_force_path == 3) return false;
-    if (g_force_path == 2) return P.n <= SMALL_SLOT_ITEMS;
+    if (g_force_path == 2) return P.n <= MEDIUM_SLOT_ITEMS;
 #endif
     return P.n <= (vargen ? SMALL_PATH_MAX_ITEMS_VARGEN : SMALL_PATH_MAX_ITEMS[P.n_eq]);
 }
@@ -841,6 +845,14 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
         (void)hipGetLastError();
         try_keys = false;
     }
+    // With affine inputs the challenge hashes do not wait for the keys to be counted: the first launch (PREP_HEAD) runs
+    // beside the key kernels, the second (PREP_TAIL) adds what only the throughput path needs.  A wire call needs its
+    // keys decoded, hence counted, before it can hash.
+#if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
+    const bool split = false;
+#else
+    const bool split = try_keys && W == nullptr;
+#endif
     if (try_keys) {
         // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
         // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
@@ -848,11 +860,18 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
         key_params Kd = K;                       // a wire call deduplicates the 32-byte encodings
         if (W)
             for (uint32_t c = 0; c < K.n_cols; ++c) { Kd.col[c].src = W->comp[c]; Kd.col[c].key_bytes = 32; }
-        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
-        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
-        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd);
-        HIP_TRY(hipEventRecord(g->key_fork, s));
-        HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
+        hipStream_t ks = split ? g->key_stream : s;          // where the keys are counted
+        if (split) {
+            HIP_TRY(hipEventRecord(g->key_fork, s));
+            HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
+        }
+        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
+        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
+        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
+        if (!split) {
+            HIP_TRY(hipEventRecord(g->key_fork, s));
+            HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
+        }
         const unsigned key_blocks = (K.n_cols * K.max_keys + BLOCK - 1) / BLOCK;
         if (W) {
             // one square root per distinct key on the key stream, while this stream decodes the key columns item by
@@ -878,9 +897,10 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
     } else if (W) {
         if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
     }
-    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P);
+    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P, split ? (int)PREP_HEAD : (int)PREP_ALL);
     if (try_keys) {
         HIP_TRY(hipStreamWaitEvent(s, g->key_join, 0));
+        if (split) hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P, (int)PREP_TAIL);
         hipLaunchKernelGGL(key_verify_kernel, dim3(grid_for(g->grid_key_verify, P.n)), dim3(BLOCK), 0, s, P, K);
     }
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(sl->grid_verify, P.n)), dim3(BLOCK), 0, s, P);

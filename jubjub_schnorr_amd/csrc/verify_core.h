@@ -743,10 +743,50 @@ struct prep_record {
 // Does this batch run the key-table path?  Decided on the device after the keys have been counted.
 JJS_HD bool keyed_mode(const verify_params& P) { return P.key_flag != nullptr && *P.key_flag != 0u; }
 
+// The device runs a batch that may take the key-table path in two launches, because whether it does is decided while
+// the first one runs (the keys are being counted beside it):
+//   PREP_HEAD  everything that does not depend on the decision: encodings, the cheap checks of the points that are not
+//              keys, the challenge;
+//   PREP_TAIL  what only the throughput path needs (the launch leaves at once when the key tables engaged): validity
+//              of the key points, half-size scalars, combined subgroup tests;
+//   PREP_ALL   both at once, with the decision already known (keyed_mode): every other caller.
+enum prep_phase : int { PREP_ALL = 0, PREP_HEAD = 1, PREP_TAIL = 2 };
+
+// validity of the points selected by `mask` (InvalidPoint takes precedence over InvalidSignature)
+JJS_HD bool points_valid(const verify_params& P, uint64_t item, uint32_t mask) {
+    bool valid = true;
+    for (uint32_t k = 0; k < P.n_points; ++k) {
+        if (!((mask >> k) & 1u)) continue;
+        fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
+        // points that come out of the wire decoder satisfy the curve equation by construction
+        valid = (P.decoded_points ? !affine_is_identity(pu, pv) : point_on_curve_not_identity(pu, pv)) && valid;
+        if ((P.own_test_mask >> k) & 1u) valid = is_torsion_free(pu, pv) && valid;
+    }
+    return valid;
+}
+// half-size scalars (shared by both equations of the double scheme) and the combined subgroup tests
+JJS_HD void scalars_and_combined_tests(const verify_params& P, uint64_t item, bool check_points, prep_record& r) {
+    const uint32_t n_eq = JJS_SKIP(P, 4u) ? 0u : P.n_eq;
+    half_scalars h{};
+    if (n_eq && P.eq[0].comb) {
+        if (JJS_SKIP(P, 8u)) {                           // profiling only: stand-in scalars, no Euclid
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h.a.w[i] = r.c.w[i] >> 2; h.b.w[i] = r.c.w[4 + i] >> 2; }
+        } else {
+            h = half_size_scalars(r.c);
+        }
+    }
+    r.h = h;
+    bool proven = true;
+    for (uint32_t k = 0; k < n_eq; ++k)
+        if (check_points && P.eq[k].comb) proven = combined_subgroup_test(P.eq[k], item, h) && proven;
+    r.proven = proven;
+}
+
 // coop: see hades_permute (the latency path's hash lanes work in groups of eight); -1 everywhere else
-JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true, int coop = -1) {
+JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true, int coop = -1, prep_phase phase = PREP_ALL) {
     prep_record r;
-    const bool keyed = keyed_mode(P);
+    const bool keyed = phase == PREP_ALL && keyed_mode(P);
     // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
     const words8 u = load_words(P.u, item);
     bool malformed = !words_lt(u, JJS_FR_WORDS);
@@ -754,17 +794,11 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     for (uint32_t e = 0; e < P.n_hash; ++e) malformed = malformed || !words_lt(load_words(P.hash_in[e], item), JJS_Q_WORDS);
     r.malformed = malformed;
 
-    // 2. point validity (InvalidPoint takes precedence over InvalidSignature)
+    // 2. point validity: a key is validated once per key on the key-table path, not per item
     const bool check_points = !JJS_SKIP(P, 1u) && !P.small_mode;
-    bool valid = true;
-    for (uint32_t k = 0; k < (check_points ? P.n_points : 0u); ++k) {
-        if (keyed && ((P.key_points_mask >> k) & 1u)) continue;      // a key: validated once per key, not per item
-        fe_n pu = load_fq(P.points[k], item), pv = load_fq(P.points[k], item, 32);
-        // points that come out of the wire decoder satisfy the curve equation by construction
-        valid = (P.decoded_points ? !affine_is_identity(pu, pv) : point_on_curve_not_identity(pu, pv)) && valid;
-        if ((P.own_test_mask >> k) & 1u) valid = is_torsion_free(pu, pv) && valid;
-    }
-    r.valid = valid;
+    const uint32_t all_points = (1u << P.n_points) - 1u;
+    const uint32_t mine = (keyed || phase == PREP_HEAD) ? (all_points & ~P.key_points_mask) : all_points;
+    r.valid = check_points ? points_valid(P, item, mine) : true;
 
     // 3. challenge
     words8 c = u;
@@ -775,22 +809,17 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
     if (P.c_out && write_c) store_words(P.c_out, item, c);
     r.c = c;
 
-    // 4. half-size scalars (shared by both equations of the double scheme) and the combined subgroup tests
-    const uint32_t n_eq = (JJS_SKIP(P, 4u) || keyed) ? 0u : P.n_eq;     // the key-table path needs neither
-    half_scalars h{};
-    if (n_eq && P.eq[0].comb) {
-        if (JJS_SKIP(P, 8u)) {                           // profiling only: stand-in scalars, no Euclid
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { h.a.w[i] = c.w[i] >> 2; h.b.w[i] = c.w[4 + i] >> 2; }
-        } else {
-            h = half_size_scalars(c);
-        }
-    }
-    r.h = h;
-    bool proven = true;
-    for (uint32_t k = 0; k < n_eq; ++k)
-        if (check_points && P.eq[k].comb) proven = combined_subgroup_test(P.eq[k], item, h) && proven;
-    r.proven = proven;
+    // 4. half-size scalars and the combined subgroup tests: the key-table path needs neither
+    r.h = half_scalars{};
+    r.proven = true;
+    if (!keyed && phase == PREP_ALL) scalars_and_combined_tests(P, item, check_points, r);
+    return r;
+}
+// PREP_TAIL: completes the record of PREP_HEAD for a batch that turned the key tables down
+JJS_HD prep_record prepare_tail(const verify_params& P, uint64_t item, prep_record r) {
+    const bool check_points = !JJS_SKIP(P, 1u) && !P.small_mode;
+    if (check_points) r.valid = points_valid(P, item, P.key_points_mask & ((1u << P.n_points) - 1u)) && r.valid;
+    scalars_and_combined_tests(P, item, check_points, r);
     return r;
 }
 

@@ -27,7 +27,7 @@ def main():
     for n in sizes:
         call = [arrays[k][:n].contiguous() for k in bench.ARG_ORDER[scheme]]
         for path, code in (("auto", 0), ("throughput", 1), ("latency-4", 0x42), ("latency-8", 0x82)):
-            if path.startswith("latency") and n > 16384:
+            if path.startswith("latency") and n > 65536:
                 continue
             _ffi.check(lib.jjs_debug_force_path(code), "force_path")
             st, _ = eng.verify(scheme, *call)

@@ -19,7 +19,8 @@ import sys
 
 # every kernel one batch launches (the key-table path adds the key_* kernels; verify_kernel then leaves at once)
 KERNELS = ("prepare_kernel", "verify_kernel", "resolve_kernel", "key_dedup_kernel", "key_assign_kernel", "key_spread_kernel",
-           "key_chain_kernel", "key_table_kernel", "key_verify_kernel")
+           "key_count_kernel", "key_scan_kernel", "key_scatter_kernel", "key_chain_kernel", "key_table_kernel", "key_verify_kernel")
+ONCE_PER_BATCH = "resolve_kernel"      # launched exactly once per batch: its launch count is the number of batches
 DOMINANT = ("key_verify_kernel", "verify_kernel")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -82,9 +83,11 @@ def main():
     for name, by_kernel in sorted(counters.items()):
         entry = {}
         total = 0.0
+        batches = len(by_kernel.get(ONCE_PER_BATCH, [])) or 1
         for k, vals in by_kernel.items():
-            entry[k] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
-            total += sum(vals) / len(vals)
+            # a kernel may be launched more than once per batch (prepare_kernel: head and tail): sum over a batch
+            entry[k] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals), "per_batch": sum(vals) / batches}
+            total += sum(vals) / batches
         entry["per_batch"] = total
         per_batch[name] = total
         summary["counters"][name] = entry
@@ -92,7 +95,8 @@ def main():
     summary["kernel_ms_rocprof"] = stats
     # key_chain / key_table run on a second stream beside prepare_kernel: the sum of the kernel times is an upper
     # bound of the batch time (bench.py's HIP-event time is the batch time)
-    batch_ms = sum(v["avg_ms"] for v in stats.values())
+    n_batches = stats.get(ONCE_PER_BATCH, {}).get("calls", 0) or 1
+    batch_ms = sum(v["avg_ms"] * v["calls"] / n_batches for v in stats.values())
     summary["batch_ms_rocprof"] = batch_ms
     summary["batch_ms_rocprof_note"] = "sum over kernels; key_chain_kernel and key_table_kernel overlap prepare_kernel"
     if "FETCH_SIZE" in per_batch and "WRITE_SIZE" in per_batch:
