@@ -839,20 +839,27 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
     HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
     key_params K{};
     bool try_keys = key_path_applies(P);
-    if (try_keys && setup_keys(P, K, s) != JJS_OK) {
+    // With affine inputs the challenge hashes do not wait for the keys to be counted: the first launch (PREP_HEAD) runs
+    // beside the key kernels (which, with the clearing of their tables, go to the key stream from the start), the second
+    // (PREP_TAIL) adds what only the throughput path needs.  A wire call needs its keys decoded, hence counted, before it
+    // can hash.
+#if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
+    const bool want_split = false;
+#else
+    const bool want_split = try_keys && W == nullptr;
+#endif
+    hipStream_t ks = want_split ? g->key_stream : s;          // where the keys are counted
+    if (want_split) {
+        HIP_TRY(hipEventRecord(g->key_fork, s));
+        HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
+    }
+    if (try_keys && setup_keys(P, K, ks) != JJS_OK) {
         // no room for the key arena (it is sized for n / 16 keys per column): the batch simply takes the throughput
         // path, as it would with keys that do not repeat
         (void)hipGetLastError();
         try_keys = false;
     }
-    // With affine inputs the challenge hashes do not wait for the keys to be counted: the first launch (PREP_HEAD) runs
-    // beside the key kernels, the second (PREP_TAIL) adds what only the throughput path needs.  A wire call needs its
-    // keys decoded, hence counted, before it can hash.
-#if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
-    const bool split = false;
-#else
-    const bool split = try_keys && W == nullptr;
-#endif
+    const bool split = want_split && try_keys;
     if (try_keys) {
         // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
         // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
@@ -860,11 +867,6 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
         key_params Kd = K;                       // a wire call deduplicates the 32-byte encodings
         if (W)
             for (uint32_t c = 0; c < K.n_cols; ++c) { Kd.col[c].src = W->comp[c]; Kd.col[c].key_bytes = 32; }
-        hipStream_t ks = split ? g->key_stream : s;          // where the keys are counted
-        if (split) {
-            HIP_TRY(hipEventRecord(g->key_fork, s));
-            HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
-        }
         hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
         hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
         hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
