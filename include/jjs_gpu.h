@@ -48,7 +48,7 @@
  * waits for the previous one, also across streams).
  *
  * Method: the engine picks, per call, from the batch size and the repetition of its keys alone (no configuration):
- * at most 32 768 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
+ * at most 16 384 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
  * ~0.85 ms var-generator up to 4 096 items); larger -> one signature per lane; at least 65 536 items whose public
  * keys (and per-item generators) repeat 16 times or more on average -> per-key tables built inside the call.  The
  * status bytes are the same on every path.

@@ -9,7 +9,7 @@
 //   key tables  (key_tables.h)    >= 65 536 items whose keys repeat >= 16 times on average: keys deduplicated on the
 //               device, validity and window tables once per key (second stream, beside the hashes), additions only
 //               per signature (key_verify_kernel); decided on the device, no host round trip;
-//   latency     (small_batch.h)   <= 32 768 items: one signature spread over 11-45 lanes in two launches.
+//   latency     (small_batch.h)   <= 16 384 items: one signature spread over 11-45 lanes in two launches.
 // The per-status tally is reduced with wave ballots and one atomic per wave per status.  One process can drive
 // several devices (jjs_init); all state is per device, per-call state lives in call slots (call_slot).
 #include <hip/hip_runtime.h>
@@ -523,13 +523,15 @@ constexpr size_t MEDIUM_SLOT_ITEMS = 131072;
 constexpr int N_BIG_SLOTS = 2;
 constexpr int SECOND_BIG_SLOT = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS;
 constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS + (N_BIG_SLOTS - 1);
-// largest batch the latency path takes, by number of equations (1: single, 2: double); above it the throughput
-// path is faster (tools/batch_size_curve.py)
-constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 32768, 32768};
+// largest batch the latency path takes, by number of equations (1: single, 2: double).  One call of 32 768 items would
+// still return sooner on this path (1.27 against 1.56 ms single; tools/batch_size_curve.py), but it does twice the work:
+// callers who keep several such calls in flight get 38 M/s from the throughput path and 28 M/s from this one
+// (tools/concurrent_calls.py), so the limit stays where the chip is not yet full
+constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
 // up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
-constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 32768, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
+constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
 struct device_state {
     int device = -1;               // HIP device ordinal
