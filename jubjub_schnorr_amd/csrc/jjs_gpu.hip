@@ -746,6 +746,7 @@ struct wire_keys {
     fe_src comp[2];          // 32-byte encodings, in the order of the scheme's key columns (eq_desc::pk_col / gen_col)
     uint8_t* out[2] = {};    // n x 64 affine
     uint8_t* bad = nullptr;  // n malformed flags
+    decode_params sig{};     // the R points of the signatures (decoded per item, beside the key kernels)
 };
 // Carves the key buffers of this call out of the slot's arena and clears the hash tables and counters.
 int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
@@ -829,9 +830,18 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
     P.prep = sl->prep;
     P.workspace = sl->workspace;
     if (int rc = begin_shared(s)) return rc;
+    auto decode_signature_points = [&]() -> int {          // wire calls: R (R') of every item
+        decode_params D = W->sig;
+        D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n)), dim3(BLOCK), 0, s, D);
+        HIP_TRY(hipGetLastError());
+        return JJS_OK;
+    };
     if (small_path_applies(P)) {
-        if (W)
+        if (W) {
+            if (int rc = decode_signature_points()) return rc;
             if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
+        }
         if (int rc = launch_small(P, s)) return rc;
         return end_shared(s);
     }
@@ -841,17 +851,17 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
     HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
     key_params K{};
     bool try_keys = key_path_applies(P);
-    // With affine inputs the challenge hashes do not wait for the keys to be counted: the first launch (PREP_HEAD) runs
-    // beside the key kernels (which, with the clearing of their tables, go to the key stream from the start), the second
-    // (PREP_TAIL) adds what only the throughput path needs.  A wire call needs its keys decoded, hence counted, before it
-    // can hash.
+    // The keys are counted (and, for a wire call, decoded once each) on the key stream from the start, with the clearing
+    // of their tables, beside the first kernel of this stream.  With affine inputs that kernel is the challenge hashes,
+    // which do not wait for the decision (PREP_HEAD; PREP_TAIL later adds what only the throughput path needs); a wire
+    // call decodes the R points of its signatures meanwhile and hashes once its keys are in place.
 #if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
-    const bool want_split = false;
+    const bool fork_keys = false;
 #else
-    const bool want_split = try_keys && W == nullptr;
+    const bool fork_keys = try_keys;
 #endif
-    hipStream_t ks = want_split ? g->key_stream : s;          // where the keys are counted
-    if (want_split) {
+    hipStream_t ks = fork_keys ? g->key_stream : s;          // where the keys are counted
+    if (fork_keys) {
         HIP_TRY(hipEventRecord(g->key_fork, s));
         HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
     }
@@ -861,7 +871,9 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
         (void)hipGetLastError();
         try_keys = false;
     }
-    const bool split = want_split && try_keys;
+    const bool split = fork_keys && try_keys && W == nullptr;
+    if (W)
+        if (int rc = decode_signature_points()) return rc;
     if (try_keys) {
         // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
         // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
@@ -872,22 +884,22 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
         hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
         hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
         hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
-        if (!split) {
+        if (!fork_keys) {
             HIP_TRY(hipEventRecord(g->key_fork, s));
             HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
         }
         const unsigned key_blocks = (K.n_cols * K.max_keys + BLOCK - 1) / BLOCK;
         if (W) {
-            // one square root per distinct key on the key stream, while this stream decodes the key columns item by
-            // item only if the batch turned the key tables down; then every item fetches its key's point
+            // one square root per distinct key on the key stream; this stream decodes the key columns item by item only
+            // if the batch turned the key tables down; then every item fetches its key's point
             key_decode_params D{};
             for (uint32_t c = 0; c < K.n_cols; ++c) D.out[c] = W->out[c];
             D.bad = W->bad;
             D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
             hipLaunchKernelGGL(key_decode_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, Kd, D);
             HIP_TRY(hipEventRecord(g->key_mid, g->key_stream));
+            HIP_TRY(hipStreamWaitEvent(s, g->key_mid, 0));               // the decision and the decoded keys
             if (int rc = launch_key_decode_per_item(P, *W, K.counters + 2, s)) return rc;
-            HIP_TRY(hipStreamWaitEvent(s, g->key_mid, 0));
             hipLaunchKernelGGL(key_unpack_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd, D);
         }
         hipLaunchKernelGGL(key_count_kernel, dim3(item_blocks), dim3(BLOCK), 0, g->key_stream, K);
@@ -1532,8 +1544,8 @@ static int wire_single_locked(const void* sig, const void* pk, const void* m, si
     decode_params D{};
     D.n_src = 1; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    if (int rc = launch_decode(D, s)) return rc;
-    wire_keys W;                                                                 // decoded by launch_verify
+    wire_keys W;                                                                 // everything is decoded by launch_verify
+    W.sig = D;
     W.n_cols = 1; W.bad = wire_bad();
     W.comp[0] = fe_src{(const uint8_t*)pk, 32, 0};  W.out[0] = wire_pts(1);      // PK
     out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
@@ -1556,8 +1568,8 @@ static int wire_double_locked(const void* sig, const void* pk, const void* m, si
     D.n_src = 2; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 96, 32}; D.out[0] = wire_pts(0);      // R
     D.src[1] = fe_src{(const uint8_t*)sig, 96, 64}; D.out[1] = wire_pts(1);      // R'
-    if (int rc = launch_decode(D, s)) return rc;
     wire_keys W;
+    W.sig = D;
     W.n_cols = 2; W.bad = wire_bad();
     W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(2);      // PK
     W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(3);      // PK'
@@ -1581,8 +1593,8 @@ static int wire_vargen_locked(const void* sig, const void* pk, const void* m, si
     decode_params D{};
     D.n_src = 1; D.n = n; D.bad = wire_bad();
     D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    if (int rc = launch_decode(D, s)) return rc;
     wire_keys W;
+    W.sig = D;
     W.n_cols = 2; W.bad = wire_bad();
     W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(1);      // PK
     W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(2);      // generator
