@@ -63,11 +63,21 @@ static void ensure_tables() {
     memcpy(g_tag, JJS_DOUBLE_TAG_WORDS, 32);
 }
 
+// jjs_host_set_split_prepare(1): the first pass in the two launches the device uses while the keys of a batch are still
+// being counted (PREP_HEAD, the record through its buffer, PREP_TAIL), instead of PREP_ALL
+static int g_split_prepare = 0;
 static void run(verify_params P) {
     std::vector<uint32_t> ws(WS_WORDS_PER_LANE + 4);
     uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+    std::vector<uint8_t> prep(65 * P.n + 64);
+    uint32_t not_keyed = 0;
+    if (g_split_prepare) {
+        P.key_flag = &not_keyed;
+        for (uint64_t i = 0; i < P.n; ++i) store_prep(prep.data(), P.n, i, prepare_item(P, i, true, -1, PREP_HEAD));
+        for (uint64_t i = 0; i < P.n; ++i) store_prep(prep.data(), P.n, i, prepare_tail(P, i, load_prep(prep.data(), P.n, i)));
+    }
     for (uint64_t i = 0; i < P.n; ++i) {
-        uint32_t st = verify_item(P, i, w);
+        uint32_t st = g_split_prepare ? finish_item(P, i, w, load_prep(prep.data(), P.n, i)) : verify_item(P, i, w);
         if (st >= ST_PENDING_EQ_FAILED) st = resolve_item(P, i, st == ST_PENDING_EQ_HELD);
         if (P.status) P.status[i] = (uint8_t)st;
         if (P.tally) P.tally[st]++;
@@ -134,7 +144,8 @@ static void run_keyed(verify_params P) {
     counters[2] = (uint32_t)w;
     P.key_flag = &counters[2];
     for (uint64_t i = 0; i < P.n; ++i) {
-        uint32_t st = kt_finish_item(P, K, i, prepare_item(P, i));
+        // the head launch alone is what the key-table path gets on the device (the tail leaves at once)
+        uint32_t st = kt_finish_item(P, K, i, g_split_prepare ? prepare_item(P, i, true, -1, PREP_HEAD) : prepare_item(P, i));
         if (st >= ST_PENDING_EQ_FAILED) st = resolve_item(P, i, st == ST_PENDING_EQ_HELD);
         if (P.status) P.status[i] = (uint8_t)st;
         if (P.tally) P.tally[st]++;
@@ -143,6 +154,10 @@ static void run_keyed(verify_params P) {
 
 extern "C" {
 
+int jjs_host_set_split_prepare(int on) {
+    g_split_prepare = on ? 1 : 0;
+    return 0;
+}
 int jjs_host_set_key_window(int w) {
     if (w != KT_WINDOW_NARROW && w != KT_WINDOW_WIDE) return -1;
     g_key_window = w;

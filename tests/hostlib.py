@@ -85,6 +85,11 @@ def comb_entry(which, i, b):
     load().jjs_host_comb_entry(which, i, b, _p(out)); return out
 
 
+def set_split_prepare(on):
+    """First pass as PREP_HEAD + PREP_TAIL (what the device launches while a batch's keys are being counted)."""
+    load().jjs_host_set_split_prepare(int(bool(on)))
+
+
 def verify(scheme, b, want_c=False):
     from helpers import ARG_ORDER
     args = [_c(b[k]) for k in ARG_ORDER[scheme]]

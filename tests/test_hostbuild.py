@@ -376,3 +376,21 @@ def test_key_table_path_matches_oracle(scheme, window):
     assert hl.verify_keyed(scheme, b, window)[0].tolist() == oracle_verify(scheme, b).tolist()
     b = torsion_grid(scheme, reps=1, extra=0 if scheme == "single" else 30)
     assert hl.verify_keyed(scheme, b, window)[0].tolist() == oracle_verify(scheme, b).tolist()
+
+
+# ---- the first pass in two launches (verify_core.h prep_phase) ---------------------------------------------
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_prepare_in_two_launches_matches_oracle(scheme):
+    """While the keys of a batch are being counted the device runs the first pass as PREP_HEAD (what does not depend on
+    the decision) and later PREP_TAIL (what only the throughput path needs), with the record stored in between: the
+    same statuses as the oracle on the throughput path, and on the key-table path, which gets the head alone."""
+    hl.set_split_prepare(True)
+    try:
+        for b in (make_batch(scheme, 60, seed=85, n_keys=4), edge_cases(scheme), torsion_grid(scheme, reps=1, extra=0 if scheme == "single" else 30)):
+            want = oracle_verify(scheme, b)
+            st, tally = hl.verify(scheme, b)
+            assert st.tolist() == want.tolist()
+            assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+            assert hl.verify_keyed(scheme, b, 6)[0].tolist() == want.tolist()
+    finally:
+        hl.set_split_prepare(False)
