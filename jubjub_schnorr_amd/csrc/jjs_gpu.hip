@@ -183,7 +183,12 @@ __global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {
 // (measured: 64 turns, +0.8 ms a batch), so the loop stops at the first key that is rare in the wave.  Every lane of
 // the wave must call it (ballots and shuffles).
 constexpr int WAVE_GROUPS = 8;
-__device__ __forceinline__ uint32_t wave_grouped_add(uint32_t* counters, uint32_t key, bool active) {
+// A batch under a few keys keeps the cursor of key k at key_cursor[k * CURSOR_STRIDE], a 64-byte line each, so that its
+// atomics do not all land on one line and one L2 channel, which the hashes running beside them also need (16 keys: 12.2 ->
+// 10.2 ms a batch); from CURSOR_DENSE_FROM keys on the cursors are dense (padded ones cost the SURVEY workload 2.7 %).
+constexpr uint32_t CURSOR_STRIDE = 16, CURSOR_DENSE_FROM = 65;
+__device__ __forceinline__ uint32_t cursor_stride(const key_params& K) { return K.counters[0] < CURSOR_DENSE_FROM ? CURSOR_STRIDE : 1u; }
+__device__ __forceinline__ uint32_t wave_grouped_add(uint32_t* counters, uint32_t stride, uint32_t key, bool active) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t leader = lane, rank = 0, size = 1;
     unsigned long long todo = __ballot(active);
@@ -202,25 +207,27 @@ __device__ __forceinline__ uint32_t wave_grouped_add(uint32_t* counters, uint32_
     }
     // all the atomics of the wave in one go: a group's leader for its group, every ungrouped lane for itself
     uint32_t base = 0;
-    if (active && lane == leader) base = atomicAdd(&counters[key], size);
+    if (active && lane == leader) base = atomicAdd(&counters[(size_t)key * stride], size);
     base = (uint32_t)__shfl((int)base, (int)leader);
     return base + rank;
 }
 __global__ __launch_bounds__(BLOCK) void key_count_kernel(key_params K) {
     if (!K.counters[2]) return;
+    const uint32_t stride = cursor_stride(K);
     const uint64_t total = (uint64_t)gridDim.x * BLOCK, first = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     for (uint64_t base = 0; base < K.n; base += total) {              // wave-uniform trip count
         const uint64_t item = base + first;
         const bool active = item < K.n;
-        (void)wave_grouped_add(K.key_cursor, active ? K.col[0].keyid[item] : 0u, active);
+        (void)wave_grouped_add(K.key_cursor, stride, active ? K.col[0].keyid[item] : 0u, active);
     }
 }
 __global__ __launch_bounds__(1024) void key_scan_kernel(key_params K) {          // one block
     if (!K.counters[2]) return;
+    const uint32_t stride = cursor_stride(K);
     __shared__ uint32_t part[1024];
     const uint32_t keys = K.counters[0], per = (keys + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < keys ? lo + per : keys;
     uint32_t sum = 0;
-    for (uint32_t k = lo; k < hi; ++k) sum += K.key_cursor[k];
+    for (uint32_t k = lo; k < hi; ++k) sum += K.key_cursor[(size_t)k * stride];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -230,15 +237,16 @@ __global__ __launch_bounds__(1024) void key_scan_kernel(key_params K) {         
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;                 // exclusive prefix of this thread's keys
-    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = K.key_cursor[k]; K.key_cursor[k] = run; run += c; }
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = K.key_cursor[(size_t)k * stride]; K.key_cursor[(size_t)k * stride] = run; run += c; }
 }
 __global__ __launch_bounds__(BLOCK) void key_scatter_kernel(key_params K) {
     if (!K.counters[2]) return;
+    const uint32_t stride = cursor_stride(K);
     const uint64_t total = (uint64_t)gridDim.x * BLOCK, first = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     for (uint64_t base = 0; base < K.n; base += total) {              // wave-uniform trip count
         const uint64_t item = base + first;
         const bool active = item < K.n;
-        const uint32_t slot = wave_grouped_add(K.key_cursor, active ? K.col[0].keyid[item] : 0u, active && !K.keep_order);
+        const uint32_t slot = wave_grouped_add(K.key_cursor, stride, active ? K.col[0].keyid[item] : 0u, active && !K.keep_order);
         if (active) K.order[K.keep_order ? (uint32_t)item : slot] = (uint32_t)item;
     }
 }
@@ -808,14 +816,15 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + 2 * pad(K.max_keys) +
                            pad(kt_base_words_for(P.n) * 4) + pad(kt_table_words_for(P.n) * 4);
-    const size_t order_bytes = pad(P.n * 4) + pad(((size_t)K.max_keys + 1) * 4);
+    const size_t cursor_words = (size_t)K.max_keys + 1 > (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE ? (size_t)K.max_keys + 1 : (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE;
+    const size_t order_bytes = pad(P.n * 4) + pad(cursor_words * 4);
     if (int rc = ensure_keys(256 + order_bytes + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
     HIP_TRY(hipMemsetAsync(K.counters, 0, 256, s));
     K.order = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
-    K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad(((size_t)K.max_keys + 1) * 4);
-    HIP_TRY(hipMemsetAsync(K.key_cursor, 0, ((size_t)K.max_keys + 1) * 4, s));
+    K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad(cursor_words * 4);
+    HIP_TRY(hipMemsetAsync(K.key_cursor, 0, cursor_words * 4, s));
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
         C.src = cols[c];

@@ -86,7 +86,8 @@ struct key_params {
     // the items grouped by their key of column 0 (counting sort on the device): lane i of key_verify_kernel takes item
     // order[i], so the lanes of a wave look up the tables of one or two keys instead of 64
     uint32_t* order;         // [n]
-    uint32_t* key_cursor;    // [max_keys + 1] items per key, then start of each key's run (advanced while scattering)
+    uint32_t* key_cursor;    // items per key, then the start of each key's run (advanced while scattering); dense, or a 64-byte
+                             // line per key when the batch has few keys (jjs_gpu.hip cursor_stride)
 };
 
 // column `idx` (0 or 1) of K, chosen field by field: indexing the kernel-argument struct with a run-time index
