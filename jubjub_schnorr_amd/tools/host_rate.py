@@ -14,6 +14,7 @@ import jubjub_schnorr_amd as jjs  # noqa: E402
 
 def main():
     log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    scheme = os.environ.get("JJS_HOST_RATE_SCHEME", "single")     # single (default, also times the wire entry point), double, vargen
     timing = len(sys.argv) > 2 and sys.argv[2] == "timing"      # profiling build: where the host time of a call goes
     from jubjub_schnorr_amd import _ffi
     if timing:
@@ -21,16 +22,16 @@ def main():
     if len(sys.argv) > 3:                                         # a variant build (A/B runs)
         _ffi.select_library(os.path.abspath(sys.argv[3]))
     eng = jjs.engine()
-    arrays, expect = bench.make_inputs(eng, "single", 1 << log2n, 0)
-    host = [arrays[k].cpu().numpy() for k in bench.ARG_ORDER["single"]]
-    eng.verify("single", *host)
+    arrays, expect = bench.make_inputs(eng, scheme, 1 << log2n, 0)
+    host = [arrays[k].cpu().numpy() for k in bench.ARG_ORDER[scheme]]
+    eng.verify(scheme, *host)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
-        st, tally = eng.verify("single", *host)
+        st, tally = eng.verify(scheme, *host)
         best = min(best, time.perf_counter() - t0)
     assert (st == expect.cpu().numpy()).all()
-    rec = {"what": "jjs_verify_single host buffers (pageable), PCIe inclusive", "items": 1 << log2n,
+    rec = {"what": f"jjs_verify_{scheme} host buffers (pageable), PCIe inclusive", "items": 1 << log2n,
            "seconds": best, "verifications_per_s": (1 << log2n) / best}
     if timing:
         import ctypes
@@ -38,6 +39,8 @@ def main():
         _ffi.check(_ffi.lib().jjs_debug_host_timing(t), "host_timing")
         rec["last_call"] = {"staging_copy_s": t[0], "waiting_for_slot_s": t[1], "total_s": t[2], "chunks": int(t[3])}
     print(json.dumps(rec), flush=True)
+    if scheme != "single":
+        return
     # the same batch as the reference serialises it (64-byte signatures, 32-byte keys): 128 instead of 196 bytes per item
     # over PCIe; on the device one square root per signature (R) and one per distinct key
     import torch
