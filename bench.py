@@ -203,6 +203,57 @@ def cpu_baseline(scheme: str, arrays: dict, gpu_status, gpu_challenge=None, budg
             "statuses_equal_gpu": agree, "challenges_equal_gpu_on_2^16_sample": c_agree}
 
 
+def host_buffer_rates(eng, scheme: str, arrays: dict, expect, calls: int = 4):
+    """Secondary figures, never `value`: the blocking host-buffer entry points on the same batch -- pageable numpy arrays
+    in, statuses out, PCIe and the staging copies included -- for the three input formats a caller can hold: affine
+    (jjs_verify_*), extended U||V||Z (jjs_verify_*_ext: what INTEGRATION.md's Rust shim passes) and wire
+    (jjs_verify_*_wire: compressed points).  One untimed call, then the mean and the best of `calls` timed ones;
+    every status of the last call is compared with the expectation."""
+    import numpy as np
+    import torch
+    n = arrays["u"].shape[0]
+    want = expect.cpu().numpy()
+    names = ARG_ORDER[scheme]
+    affine = [arrays[k].cpu().numpy() for k in names]
+    zgen = torch.Generator(device="cpu").manual_seed(SEED + 99)
+
+    def to_ext(pts):
+        z = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=zgen)
+        z[:, 31] &= 0x3F; z[:, 0] |= 1
+        z = z.cuda()
+        U = eng.debug_fq_mul(pts[:, :32].contiguous(), z)
+        V = eng.debug_fq_mul(pts[:, 32:].contiguous(), z)
+        return torch.cat([U, V, z], 1).contiguous().cpu().numpy()
+    ext = [to_ext(arrays[k]) if arrays[k].shape[1] == 64 else arrays[k].cpu().numpy() for k in names]
+    c = {k: eng.compress(v) for k, v in arrays.items() if v.shape[1] == 64}
+    if scheme == "single":
+        wire = [torch.cat([arrays["u"], c["R"]], 1), c["PK"], arrays["m"]]
+    elif scheme == "double":
+        wire = [torch.cat([arrays["u"], c["R"], c["Rp"]], 1), torch.cat([c["PK"], c["PKp"]], 1), arrays["m"]]
+    else:
+        wire = [torch.cat([arrays["u"], c["R"]], 1), torch.cat([c["PK"], c["Gen"]], 1), arrays["m"]]
+    wire = [w.contiguous().cpu().numpy() for w in wire]
+    torch.cuda.synchronize()
+    out, ok = {}, True
+    for fmt, fn, args, nbytes in (("affine", lambda *a: eng.verify(scheme, *a), affine, ALGO_BYTES[scheme]),
+                                  ("ext", lambda *a: eng.verify_ext(scheme, *a), ext, EXT_BYTES[scheme]),
+                                  ("wire", lambda *a: eng.verify_wire(scheme, *a), wire, WIRE_BYTES[scheme])):
+        fn(*args)
+        times = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            st, tally = fn(*args)
+            times.append(time.perf_counter() - t0)
+        good = bool((st == want).all()) and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+        ok = ok and good
+        mean = sum(times) / len(times)
+        out[fmt] = {"value": n / mean, "best": n / min(times), "unit": "verifications/s", "ms_per_call": mean * 1e3,
+                    "bytes_per_item_over_pcie": nbytes, "bit_exact": good}
+    out["note"] = ("blocking jjs_verify_%s{,_ext,_wire} on pageable host arrays of the same batch, PCIe inclusive, mean of %d calls; "
+                   "never `value`" % (scheme, calls))
+    return out, ok
+
+
 def csrc_hash() -> str:
     """SHA-256 over the kernel sources: ties a committed PMC profile to the code it was taken from."""
     import hashlib
@@ -379,6 +430,9 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
                                         "bit_exact": bool(ok2),
                                         "note": "same K batches, issued alternately on two streams (two in flight); not the headline value"}
         ok = ok and ok2
+    if world == 1 and not (args.wire or args.ext or args.no_host_buffers) and n_keys == N_KEYS:
+        rec["host_buffer"], okh = host_buffer_rates(eng, scheme, arrays, expect)
+        ok = ok and okh
     if with_cpu:
         gpu_c = eng.challenge(scheme, *[arrays[k][: 1 << 16] for k in ARG_ORDER[scheme][1:]])
         rec["cpu_baseline"] = cpu_baseline(scheme, arrays, st, gpu_c)
@@ -397,6 +451,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the secondary two-stream figure (profiling passes: overlapping kernels would blur per-kernel times)")
+    ap.add_argument("--no-host-buffers", action="store_true",
+                    help="skip the secondary host-buffer figures (profiling passes)")
     ap.add_argument("--wire", action="store_true",
                     help="feed the reference's wire formats (compressed points, decoded on the device)")
     ap.add_argument("--ext", action="store_true",
@@ -485,6 +541,8 @@ def main():
             out["cpu_baseline"] = head["cpu_baseline"]
         if "pipelined_two_streams" in head:
             out["pipelined_two_streams"] = head["pipelined_two_streams"]
+        if "host_buffer" in head:
+            out["host_buffer"] = head["host_buffer"]
         if len(schemes) > 1:        # BASELINE.json metric: "single + double" (and configs[4], the per-item generator)
             out["schemes"] = {s: records[s] for s in schemes[1:]}
         if unique is not None:

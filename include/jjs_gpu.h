@@ -114,6 +114,26 @@ int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const vo
                           void* status, void* tally, void* stream);
 int jjs_stream_sync(void* stream);
 
+/* Which method the calls on the calling thread's device took since jjs_init (the engine chooses per call; see "Method"
+ * above): out[k] = number of calls, k one of the JJS_PATH_* indices; out[JJS_PATH_KEY_POOL_BYTES] = device memory the
+ * per-key tables hold right now.  A call that tried the key tables is counted under what the device decided for it
+ * (WIDE / NARROW: tables with 6- / 5-bit windows; DO_NOT_REPEAT: fewer than 16 signatures per key on average;
+ * PROBE_LIMIT: keys that collide in the dedup table; POOL_TOO_SMALL: the keys repeat but their tables did not fit -- the
+ * pool has grown by the slot's next call; the last three ran the throughput path) once that call has finished; NO_MEMORY
+ * counts allocations of the table pool that the device refused (those calls ran the throughput path, too).  So a caller
+ * can see when its batches fall off the fast path.  Host-buffer calls count once per device block. */
+#define JJS_PATH_LATENCY 0
+#define JJS_PATH_THROUGHPUT 1
+#define JJS_PATH_KEY_TABLES_WIDE 2
+#define JJS_PATH_KEY_TABLES_NARROW 3
+#define JJS_PATH_KEYS_DO_NOT_REPEAT 4
+#define JJS_PATH_KEYS_PROBE_LIMIT 5
+#define JJS_PATH_KEYS_POOL_TOO_SMALL 6
+#define JJS_PATH_KEYS_NO_MEMORY 7
+#define JJS_PATH_KEY_POOL_BYTES 8
+#define JJS_PATH_STATS 9
+int jjs_path_stats(uint64_t out[JJS_PATH_STATS]);
+
 /* ---- wire formats (reference `to_bytes` / `from_bytes`), device buffers, asynchronous ------------------
  * Points travel compressed (32 bytes: little-endian v, parity of u in bit 255) and are decoded on the
  * device; an item with any undecodable point (v >= q, no square root, or u = 0 with the sign bit set)

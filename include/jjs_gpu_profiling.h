@@ -29,8 +29,14 @@ int jjs_debug_force_path(int which);
  * devices (own stream, tables, workspace, staging each) that share the visible cards round-robin; the tallies are
  * then summed on the host, since two ranks on one card cannot form an RCCL clique. */
 int jjs_debug_allow_virtual_devices(int allow);
+/* on != 0: the next calls find that the pool of the per-key tables "cannot be allocated" (the branch a device short of
+ * memory takes): they run the throughput path; 0 restores the product behaviour. */
+int jjs_debug_fail_key_arena(int on);
+/* on != 0: the dedup hash of the key tables runs with seed 0 instead of a fresh seed per call, so that a test can
+ * present keys crafted to collide in it (what the seed keeps a sender from doing). */
+int jjs_debug_pin_hash_seed(int on);
 /* Where the last host-buffer call on one device spent its host time: out[0] seconds copying the caller's arrays into
- * the pinned slots, out[1] seconds waiting for a slot's previous upload, out[2] seconds in all, out[3] chunks. */
+ * the pinned slots, out[1] seconds waiting for a slot's previous upload, out[2] seconds in all, out[3] pieces. */
 int jjs_debug_host_timing(double out[4]);
 
 #ifdef __cplusplus

@@ -30,6 +30,7 @@ SIGNATURES = {
     "jjs_verify_double_dev": [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_vargen_dev": [_P, _P, _P, _P, _P, _Z, _P, _P, _P],
     "jjs_stream_sync": [_P],
+    "jjs_path_stats": [_P],
     "jjs_verify_single_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_double_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_vargen_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
@@ -66,6 +67,8 @@ PROFILING_SIGNATURES = {
     "jjs_debug_allow_virtual_devices": [_I],
     "jjs_debug_force_path": [_I],
     "jjs_debug_host_timing": [_P],
+    "jjs_debug_fail_key_arena": [_I],
+    "jjs_debug_pin_hash_seed": [_I],
 }
 _RESTYPES = {"jjs_shutdown": None, "jjs_last_error": ctypes.c_char_p, "jjs_debug_comb_table_bytes": _Z}
 

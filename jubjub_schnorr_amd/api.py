@@ -133,6 +133,16 @@ class Engine:
                       tally.ctypes.data_as(ctypes.c_void_p)), f"jjs_verify_{scheme}{suffix}")
         return status, tally
 
+    PATH_STAT_NAMES = ("latency", "throughput", "key_tables_wide", "key_tables_narrow", "keys_do_not_repeat",
+                       "keys_probe_limit", "keys_pool_too_small", "keys_no_memory", "key_pool_bytes")
+
+    def path_stats(self) -> dict:
+        """Which method the calls on the current device took so far (jjs_path_stats): calls per path, and the bytes the
+        per-key tables hold.  Calls still running are not in yet."""
+        out = (ctypes.c_uint64 * len(self.PATH_STAT_NAMES))()
+        _ffi.check(self._lib.jjs_path_stats(out), "jjs_path_stats")
+        return dict(zip(self.PATH_STAT_NAMES, (int(v) for v in out)))
+
     _WIRE_WIDTHS = {"single": (64, 32, 32), "double": (96, 64, 32), "vargen": (64, 64, 32)}
 
     def verify_wire(self, scheme: str, sig, pk, m, want_status: bool = True):

@@ -19,11 +19,16 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <random>
 #include <sched.h>
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 #include <rccl/rccl.h>
 
 #include "../../include/jjs_gpu.h"
@@ -46,12 +51,16 @@ constexpr int BLOCK = 256;
 // per-lane workspace, about half the registers of verify_kernel: four waves per SIMD.
 // phase: PREP_ALL, or PREP_HEAD / PREP_TAIL for a batch whose keys are still being counted when the launch starts
 // (verify_core.h prep_phase); the tail leaves at once when the key tables engaged.
-__global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P, int phase) {
+// The launch covers the items [first, first + count) of the batch: a host-buffer call hashes its items range by range
+// while the later ranges are still being uploaded (run_host_block); every other call passes (0, n).
+__global__ __launch_bounds__(BLOCK, 4) void prepare_kernel(verify_params P, int phase, uint64_t first, uint64_t count) {
     if (phase == PREP_TAIL && keyed_mode(P)) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total)
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += total) {
+        const uint64_t item = first + i;
         store_prep(P.prep, P.n, item, phase == PREP_TAIL ? prepare_tail(P, item, load_prep(P.prep, P.n, item))
                                                          : prepare_item(P, item, true, -1, (prep_phase)phase));
+    }
 }
 
 // What a first-pass lane does with its verdict: final statuses go to the caller's array and the tally (wave
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {
         for (uint32_t c = 0; c < K.n_cols; ++c) {
             const key_column C = kt_col(K, (int32_t)c);
-            uint32_t slot = (uint32_t)kt_hash(C.src, item, C.key_bytes) & C.hash_mask;
+            uint32_t slot = (uint32_t)kt_hash(C.src, item, C.key_bytes, K.seed) & C.hash_mask;
             uint32_t rep = (uint32_t)item;
             bool settled = false;
             // every probe either claims a slot or meets a settled one; the table has at least 2 n slots, so honest
@@ -143,11 +152,17 @@ __global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     if (blockIdx.x == 0 && threadIdx.x == 0) {              // the decision: enough signatures per key in every column
         bool use = K.counters[3] == 0u, wide = true;       // no probe sequence was cut short
+        bool fits_narrow = true;
         for (uint32_t c = 0; c < K.n_cols; ++c) {
             use = use && (uint64_t)K.counters[c] * KT_MIN_MULTIPLICITY <= K.n;
-            wide = wide && (uint64_t)K.counters[c] * KT_WIDE_MULTIPLICITY <= K.n;
+            // wide windows where the keys repeat enough to repay them AND the slot's table pool holds that many wide tables
+            wide = wide && (uint64_t)K.counters[c] * KT_WIDE_MULTIPLICITY <= K.n && K.counters[c] <= K.max_keys_wide;
+            fits_narrow = fits_narrow && K.counters[c] <= K.max_keys;
         }
         const uint32_t w = (wide && K.force_window != (uint32_t)KT_WINDOW_NARROW) ? KT_WINDOW_WIDE : KT_WINDOW_NARROW;
+        // keys that repeat but whose tables do not fit the pool: this batch takes the throughput path, the host reads
+        // counters[4] back after the call and the pool has grown by the next one (note_key_feedback)
+        if (use && w == (uint32_t)KT_WINDOW_NARROW && !fits_narrow) { use = false; K.counters[4] = 1u; }
         K.counters[2] = use ? w : 0u;                      // ... and the window width of the tables
     }
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
@@ -395,7 +410,8 @@ struct decode_params {
     uint8_t* out[4];      // affine u || v, n x 64 each
     uint8_t* bad;         // n bytes, set to 1 when any source of item i fails to decode (nullable)
     uint8_t* ok;          // n bytes, 1/0 per item for source 0 (nullable; debug entry point)
-    uint64_t n;
+    uint64_t n;           // items of this launch: first .. first + n - 1
+    uint64_t first;
     dlog_tables dlog;
     const uint32_t* skip_flag;   // nullable: the launch leaves at once when the word is non-zero (keys decoded per key instead)
 };
@@ -406,7 +422,8 @@ __global__ __launch_bounds__(BLOCK) void dlog_table_kernel(uint32_t* pow, uint8_
 __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
     if (P.skip_flag && *P.skip_flag) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < P.n; item += total) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += total) {
+        const uint64_t item = P.first + i;
         bool all_ok = true;
         for (uint32_t k = 0; k < P.n_src; ++k) {
             decoded_point d = decompress_point(load_words(P.src[k], item), P.dlog);
@@ -430,11 +447,11 @@ __global__ __launch_bounds__(BLOCK) void key_decode_kernel(key_params K, key_dec
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, c = t / K.max_keys, id = t % K.max_keys;
     if (c < K.n_cols && id < K.counters[c]) kt_decode_key(kt_col(K, (int32_t)c), id, c == 0 ? D.out[0] : D.out[1], D.dlog);
 }
-__global__ __launch_bounds__(BLOCK) void key_unpack_kernel(key_params K, key_decode_params D) {
+__global__ __launch_bounds__(BLOCK) void key_unpack_kernel(key_params K, key_decode_params D, uint64_t first, uint64_t count) {
     if (!K.counters[2]) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total)
-        for (uint32_t c = 0; c < K.n_cols; ++c) kt_unpack_item(kt_col(K, (int32_t)c), item, c == 0 ? D.out[0] : D.out[1], D.bad);
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += total)
+        for (uint32_t c = 0; c < K.n_cols; ++c) kt_unpack_item(kt_col(K, (int32_t)c), first + i, c == 0 ? D.out[0] : D.out[1], D.bad);
 }
 // (U, V, Z) -> affine for the *_ext entry points: every lane owns the items lane, lane + lanes, ... and shares one
 // field inversion among them (normalize.h)
@@ -542,6 +559,75 @@ __global__ __launch_bounds__(BLOCK) void dbg_half_scalars_kernel(const uint8_t* 
 // calls of at most MEDIUM_SLOT_ITEMS: calls in different slots touch disjoint buffers and are not ordered against
 // each other, so small and medium calls issued on different streams overlap on the device; calls that share a slot
 // are ordered by its event.
+// Helper threads of the host-buffer entry points (pageable -> pinned staging copies; one thread moves ~11 GB/s).  They are
+// started once per device and parked on a condition variable between pieces; a thread that cannot be created is simply
+// missing (the caller takes its share), nothing here throws past the extern "C" boundary.
+class staging_pool {
+    std::mutex mu;
+    std::condition_variable work_cv, done_cv;
+    std::vector<std::thread> threads;
+    void (*fn)(void*, unsigned) = nullptr;
+    void* ctx = nullptr;
+    unsigned tasks = 0, next = 0, running = 0;
+    uint64_t epoch = 0;
+    bool quit = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        uint64_t seen = 0;
+        for (;;) {
+            work_cv.wait(lk, [&] { return quit || (epoch != seen && next < tasks); });
+            if (quit) return;
+            seen = epoch;
+            while (next < tasks) {
+                const unsigned t = next++;
+                ++running;
+                lk.unlock();
+                fn(ctx, t);
+                lk.lock();
+                --running;
+            }
+            if (running == 0) done_cv.notify_all();
+        }
+    }
+public:
+    explicit staging_pool(unsigned helpers) {
+        for (unsigned i = 0; i < helpers; ++i) {
+            try { threads.emplace_back([this] { loop(); }); } catch (...) { break; }
+        }
+    }
+    ~staging_pool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        work_cv.notify_all();
+        for (std::thread& t : threads) t.join();
+    }
+    unsigned helpers() const { return (unsigned)threads.size(); }
+    // f(c, t) for t = 0 .. T-1: begin() hands the tasks to the helpers and returns; join() lets the caller take what is
+    // left and returns when every task is done.  One batch of tasks at a time.
+    void begin(unsigned T, void (*f)(void*, unsigned), void* c) {
+        std::lock_guard<std::mutex> lk(mu);
+        fn = f; ctx = c; tasks = T; next = 0; ++epoch;
+        work_cv.notify_all();
+    }
+    void join() {
+        std::unique_lock<std::mutex> lk(mu);
+        while (next < tasks) {
+            const unsigned t = next++;
+            ++running;
+            lk.unlock();
+            fn(ctx, t);
+            lk.lock();
+            --running;
+        }
+        done_cv.wait(lk, [&] { return running == 0; });
+        tasks = 0; fn = nullptr; ctx = nullptr;
+    }
+};
+
+// What the last key-table attempt of a slot found (key_params::counters), copied to pinned host memory behind the call:
+// the host reads it before the slot's next attempt (note_key_feedback) -- no call ever waits for it.
+struct key_feedback {
+    uint32_t counters[8];
+};
 struct call_slot {
     uint32_t* workspace = nullptr;    // WS_WORDS_PER_LANE words per lane of the verify grid
     int grid_verify = 0;              // blocks of verify_kernel that fit this workspace
@@ -553,8 +639,21 @@ struct call_slot {
     size_t wire_items = 0;
     uint8_t* small = nullptr;         // latency path: window tables of the chain lanes + per-point verdicts (grow-only)
     size_t small_bytes = 0;
-    uint8_t* keys = nullptr;          // key-table path: hash tables, key ids, bases and window tables per key (grow-only)
+    // key-table path (big and medium slots).  Two arenas, both grow-only: the index (hash tables, key ids, item order:
+    // sized by the batch) and the pool of per-key bases and window tables, which is sized by the number of distinct keys
+    // the slot's calls have carried -- KEY_POOL_INITIAL_BYTES to begin with, more once a call has shown that it needs more.
+    uint8_t* keys = nullptr;
     size_t keys_bytes = 0;
+    uint8_t* key_pool = nullptr;
+    size_t key_pool_bytes = 0;
+    size_t key_pool_want = 0;         // what the last call that found the pool too small would have needed
+    size_t key_pool_refused = 0;      // a size hipMalloc turned down (not asked for again)
+    key_feedback* seen = nullptr;     // pinned host memory
+    bool seen_pending = false;        // `seen` is being written by a call that may still run (its end: last_use)
+    uint64_t seen_n = 0;              // ... whose batch had this many items in
+    uint32_t seen_cols = 0;           // ... this many key columns
+    hipStream_t key_stream = nullptr; // the per-key kernels of the slot's call run here, beside the challenge hashes
+    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr;
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
     hipStream_t last_stream = nullptr;// ... and the stream it was issued on
 };
@@ -580,12 +679,17 @@ constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
 constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
+constexpr size_t HOST_MAX_PIECES = 40;      // pieces a host-buffer call uploads its block in (plan_pieces)
+#ifndef JJS_HOST_SIDE_STREAMS
+#define JJS_HOST_SIDE_STREAMS 3
+#endif
+constexpr int HOST_SIDE_STREAMS = JJS_HOST_SIDE_STREAMS;
 struct device_state {
     int device = -1;               // HIP device ordinal
     call_slot slots[N_SLOTS];          // [0] big, then the small ones, then the medium ones, then the second big one
     unsigned next_small = 0, next_medium = 0, next_big = 0;
     hipStream_t stream = nullptr;  // used by the host-buffer entry points
-    hipStream_t stream2 = nullptr; // ... whose chunks alternate between the two
+    hipStream_t side[HOST_SIDE_STREAMS] = {};   // ... whose ranges go to `stream` and these in turn (run_host_block)
     hipEvent_t host_begin = nullptr;
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
@@ -599,14 +703,16 @@ struct device_state {
     uint8_t* msig = nullptr;       // multisig scratch
     size_t msig_items = 0, msig_transcripts = 0;
     int grid_msig = 0;
-    hipStream_t key_stream = nullptr;    // key-table path: the per-key kernels run here, beside the challenge hashes
-    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr;
+    int key_priority = 0;                // stream priority of the slots' key streams
+    uint64_t stats[JJS_PATH_STATS] = {}; // jjs_path_stats: which path the calls on this device took
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
+    hipEvent_t side_join = nullptr, ingest_done = nullptr;
+    staging_pool* stagers = nullptr;     // host-buffer calls: the threads that copy pageable -> pinned with the caller's
     uint8_t* stage = nullptr;            // host-buffer calls: device copies of the inputs + statuses (grow-only)
     size_t stage_bytes = 0;
     uint8_t* pinned = nullptr;           // host-buffer calls: pinned host staging (two input slots + statuses, grow-only)
     size_t pinned_bytes = 0;
-    hipEvent_t chunk_up[33] = {}, chunk_done[33] = {};
+    hipEvent_t chunk_up[HOST_MAX_PIECES] = {}, chunk_done[HOST_MAX_PIECES] = {};   // per piece of a host-buffer call: uploaded, converted
 };
 
 // RCCL is needed only when one process drives several devices, so it is loaded on demand.
@@ -674,6 +780,8 @@ int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (
 double g_host_timing[4] = {0, 0, 0, 0};   // last host-buffer call: seconds staging, waiting for slots, total; chunks
 bool g_keep_order = false;        // ... 0x1000: key-table path without grouping the items by key
 int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
+bool g_fail_key_arena = false;    // set by jjs_debug_fail_key_arena: the key-table pool "cannot be allocated"
+bool g_pin_hash_seed = false;     // set by jjs_debug_pin_hash_seed: the dedup hash runs with seed 0
 #endif
 
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
@@ -767,7 +875,72 @@ int launch_small(verify_params P, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }
-int ensure_keys(size_t bytes) {
+// ---- key-table path: arenas ------------------------------------------------------------------------------
+// Batches of at least this many items (big or medium slot) try the key tables.
+constexpr size_t KT_MIN_ITEMS = 65536;
+// The table pool a slot starts with: SURVEY.md 8(d)'s 4 096 keys with wide windows are 0.86 GB per column, two columns
+// (double, var-gen) 1.73 GB.  A call whose keys repeat but need more leaves a note (key_feedback) and the pool has grown
+// by the slot's next call; until then the call runs the throughput path, as it would with keys that do not repeat.
+constexpr size_t KEY_POOL_INITIAL_BYTES = size_t(1792) << 20;
+size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// One column's share of the pool: key_item / flags per key, then bases and tables in the proportion narrow windows
+// need (1 : 17); wide windows (1 : 33) then fill 97 % of the same regions.
+struct pool_layout {
+    size_t item_bytes, flag_bytes, base_bytes, table_bytes;
+    uint32_t cap_narrow, cap_wide;      // keys whose bases and tables fit, by window width
+};
+pool_layout key_pool_layout(size_t col_bytes) {
+    pool_layout L{};
+    const size_t per_narrow = kt_key_bytes(KT_WINDOW_NARROW) + 8;
+    const size_t cap = col_bytes > 4096 ? (col_bytes - 4096) / per_narrow : 0;
+    L.cap_narrow = (uint32_t)(cap < 0x7fffffffu ? cap : 0x7fffffffu);
+    L.item_bytes = pad256((size_t)L.cap_narrow * 4);
+    L.flag_bytes = pad256(L.cap_narrow);
+    L.base_bytes = pad256((size_t)L.cap_narrow * kt_positions(KT_WINDOW_NARROW) * KT_BASE_WORDS * 4);
+    const size_t used = L.item_bytes + 2 * L.flag_bytes + L.base_bytes;
+    L.table_bytes = col_bytes > used ? (col_bytes - used) & ~size_t(255) : 0;
+    const size_t by_base = L.base_bytes / ((size_t)kt_positions(KT_WINDOW_WIDE) * KT_BASE_WORDS * 4);
+    const size_t by_table = L.table_bytes / ((size_t)kt_positions(KT_WINDOW_WIDE) * kt_table_words(KT_WINDOW_WIDE) * 4);
+    L.cap_wide = (uint32_t)(by_base < by_table ? by_base : by_table);
+    if ((size_t)L.cap_narrow * kt_positions(KT_WINDOW_NARROW) * kt_table_words(KT_WINDOW_NARROW) * 4 > L.table_bytes) L.cap_narrow = 0;   // cannot happen (see per_narrow)
+    return L;
+}
+// the pool size at which `cols` columns hold `keys` keys each (wide or narrow windows), with some headroom
+size_t key_pool_bytes_for(uint32_t cols, uint64_t keys, bool wide) {
+    const uint64_t want = keys + keys / 16 + 16;
+    size_t col = (size_t)want * (kt_key_bytes(wide ? KT_WINDOW_WIDE : KT_WINDOW_NARROW) + 8) + 8192;
+    for (int i = 0; i < 64; ++i) {
+        const pool_layout L = key_pool_layout(col);
+        if ((wide ? L.cap_wide : L.cap_narrow) >= want) break;
+        col += col / 32 + 4096;
+    }
+    return pad256(col) * cols;
+}
+
+// Reads what the slot's previous key-table attempt left in pinned memory (if that call has ended): the path
+// statistics, and the pool size a turned-down batch would have needed.
+void note_key_feedback() {
+    if (!sl->seen_pending || hipEventQuery(sl->last_use) != hipSuccess) return;
+    sl->seen_pending = false;
+    const uint32_t* c = sl->seen->counters;
+    if (c[2] == (uint32_t)KT_WINDOW_WIDE) ++g->stats[JJS_PATH_KEY_TABLES_WIDE];
+    else if (c[2] == (uint32_t)KT_WINDOW_NARROW) ++g->stats[JJS_PATH_KEY_TABLES_NARROW];
+    else if (c[3]) ++g->stats[JJS_PATH_KEYS_PROBE_LIMIT];
+    else if (c[4]) {
+        ++g->stats[JJS_PATH_KEYS_POOL_TOO_SMALL];
+        uint64_t most = 0;
+        bool wide = true;
+        for (uint32_t k = 0; k < sl->seen_cols && k < 2; ++k) {
+            most = c[k] > most ? c[k] : most;
+            wide = wide && (uint64_t)c[k] * KT_WIDE_MULTIPLICITY <= sl->seen_n;
+        }
+        const size_t want = key_pool_bytes_for(sl->seen_cols, most, wide);
+        if (want > sl->key_pool_want) sl->key_pool_want = want;
+    } else ++g->stats[JJS_PATH_KEYS_DO_NOT_REPEAT];
+}
+
+int ensure_key_index(size_t bytes) {
     if (bytes <= sl->keys_bytes) return JJS_OK;
     if (sl->keys) {
         HIP_TRY(hipDeviceSynchronize());
@@ -778,16 +951,40 @@ int ensure_keys(size_t bytes) {
     sl->keys_bytes = bytes;
     return JJS_OK;
 }
-// Batches of at least this many items (big or medium slot): the per-key tables are sized for n / KT_MIN_MULTIPLICITY keys per column.
-constexpr size_t KT_MIN_ITEMS = 65536;
+// The pool grows when a call has asked for more; when hipMalloc says no, the pool the slot has stays (and that size
+// is not asked for again).  Nothing is freed before its replacement exists.
+int ensure_key_pool() {
+#if defined(JJS_PROFILING)
+    if (g_fail_key_arena) return fail(JJS_ERR_HIP, "key arena allocation failed (jjs_debug_fail_key_arena)");
+#endif
+    size_t want = sl->key_pool_want > KEY_POOL_INITIAL_BYTES ? sl->key_pool_want : KEY_POOL_INITIAL_BYTES;
+    const bool refused = sl->key_pool_refused && want >= sl->key_pool_refused;     // hipMalloc has said no to this much before
+    if (sl->key_pool && (want <= sl->key_pool_bytes || refused)) return JJS_OK;
+    if (!sl->key_pool && refused) want = KEY_POOL_INITIAL_BYTES;
+    uint8_t* fresh = nullptr;
+    if (hipMalloc(&fresh, want) != hipSuccess) {
+        (void)hipGetLastError();
+        sl->key_pool_refused = want;
+        ++g->stats[JJS_PATH_KEYS_NO_MEMORY];
+        return sl->key_pool ? JJS_OK : fail(JJS_ERR_HIP, "hipMalloc of the key-table pool (%zu bytes) failed", want);
+    }
+    if (sl->key_pool) {
+        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old pool
+        HIP_TRY(hipFree(sl->key_pool));
+    }
+    sl->key_pool = fresh;
+    sl->key_pool_bytes = want;
+    return JJS_OK;
+}
+
 bool key_path_applies(const verify_params& P) {
 #if defined(JJS_PROFILING)
     if (g_force_path == 3) return false;           // throughput path without the key tables
 #endif
-    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && P.n_eq >= 1;
+    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && P.n_eq >= 1 && sl->key_stream != nullptr;
 }
-// The compressed key columns of a wire call: launch_verify decodes them, once per key when the key tables engage and
-// once per item otherwise, into the affine columns the scheme descriptor already points at.
+// The compressed key columns of a wire call: decoded once per key when the key tables engage and once per item
+// otherwise, into the affine columns the scheme descriptor already points at.
 struct wire_keys {
     uint32_t n_cols = 0;
     fe_src comp[2];          // 32-byte encodings, in the order of the scheme's key columns (eq_desc::pk_col / gen_col)
@@ -795,13 +992,23 @@ struct wire_keys {
     uint8_t* bad = nullptr;  // n malformed flags
     decode_params sig{};     // the R points of the signatures (decoded per item, beside the key kernels)
 };
-// Carves the key buffers of this call out of the slot's arena and clears the hash tables and counters.
+uint64_t next_seed() {       // per-call seed of the dedup hash: unpredictable to whoever chose the keys
+    static std::mt19937_64 rng = [] {
+        std::random_device rd;
+        std::seed_seq seq{rd(), rd(), rd(), rd(), (unsigned)std::chrono::steady_clock::now().time_since_epoch().count()};
+        return std::mt19937_64(seq);
+    }();
+    return rng();
+}
+// Carves the key buffers of this call out of the slot's two arenas and clears the hash tables and counters (on `s`).
 int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
+    note_key_feedback();
     K.n = P.n;
-    K.max_keys = (uint32_t)(P.n / KT_MIN_MULTIPLICITY);
+    K.seed = next_seed();
 #if defined(JJS_PROFILING)
     K.force_window = (uint32_t)g_force_window;
     K.keep_order = g_keep_order ? 1u : 0u;
+    if (g_pin_hash_seed) K.seed = 0;
 #endif
     // key columns: PK of every equation, and the generator where it is per-item data
     fe_src cols[2];
@@ -811,33 +1018,39 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
         if (!P.eq[e].comb) { cols[P.eq[e].gen_col] = P.eq[e].gen; n_cols = n_cols > (uint32_t)P.eq[e].gen_col + 1 ? n_cols : (uint32_t)P.eq[e].gen_col + 1; }
     }
     K.n_cols = n_cols;
+    if (int rc = ensure_key_pool()) return rc;
+    const size_t col_bytes = (sl->key_pool_bytes / n_cols) & ~size_t(255);
+    const pool_layout L = key_pool_layout(col_bytes);
+    const uint64_t most = P.n / KT_MIN_MULTIPLICITY;            // more keys than this never take the path
+    K.max_keys = (uint32_t)(L.cap_narrow < most ? L.cap_narrow : most);
+    K.max_keys_wide = L.cap_wide;
+    if (K.max_keys == 0) return fail(JJS_ERR_HIP, "key-table pool too small");
     size_t slots = 1;
     while (slots < 2 * P.n) slots <<= 1;
-    auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t per_col = pad(slots * 4) + 2 * pad(P.n * 4) + pad((size_t)K.max_keys * 4) + 2 * pad(K.max_keys) +
-                           pad(kt_base_words_for(P.n) * 4) + pad(kt_table_words_for(P.n) * 4);
+    const size_t per_col = pad256(slots * 4) + 2 * pad256(P.n * 4);
     const size_t cursor_words = (size_t)K.max_keys + 1 > (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE ? (size_t)K.max_keys + 1 : (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE;
-    const size_t order_bytes = pad(P.n * 4) + pad(cursor_words * 4);
-    if (int rc = ensure_keys(256 + order_bytes + n_cols * per_col)) return rc;
+    const size_t order_bytes = pad256(P.n * 4) + pad256(cursor_words * 4);
+    if (int rc = ensure_key_index(256 + order_bytes + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
     HIP_TRY(hipMemsetAsync(K.counters, 0, 256, s));
-    K.order = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
-    K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad(cursor_words * 4);
+    K.order = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
+    K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad256(cursor_words * 4);
     HIP_TRY(hipMemsetAsync(K.key_cursor, 0, cursor_words * 4, s));
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
         C.src = cols[c];
         C.key_bytes = 64;
-        C.hash = reinterpret_cast<uint32_t*>(p); C.hash_mask = (uint32_t)(slots - 1); p += pad(slots * 4);
+        C.hash = reinterpret_cast<uint32_t*>(p); C.hash_mask = (uint32_t)(slots - 1); p += pad256(slots * 4);
         HIP_TRY(hipMemsetAsync(C.hash, 0, slots * 4, s));
-        C.rep = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
-        C.keyid = reinterpret_cast<uint32_t*>(p); p += pad(P.n * 4);
-        C.key_item = reinterpret_cast<uint32_t*>(p); p += pad((size_t)K.max_keys * 4);
-        C.key_flags = p; p += pad(K.max_keys);
-        C.key_undecodable = p; p += pad(K.max_keys);
-        C.bases = reinterpret_cast<uint32_t*>(p); p += pad(kt_base_words_for(P.n) * 4);
-        C.tables = reinterpret_cast<uint32_t*>(p); p += pad(kt_table_words_for(P.n) * 4);
+        C.rep = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
+        C.keyid = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
+        uint8_t* q = sl->key_pool + (size_t)c * col_bytes;
+        C.key_item = reinterpret_cast<uint32_t*>(q); q += L.item_bytes;
+        C.key_flags = q; q += L.flag_bytes;
+        C.key_undecodable = q; q += L.flag_bytes;
+        C.bases = reinterpret_cast<uint32_t*>(q); q += L.base_bytes;
+        C.tables = reinterpret_cast<uint32_t*>(q);
     }
     return JJS_OK;
 }
@@ -855,22 +1068,70 @@ bool small_path_applies(const verify_params& P) {
     return P.n <= (vargen ? SMALL_PATH_MAX_ITEMS_VARGEN : SMALL_PATH_MAX_ITEMS[P.n_eq]);
 }
 
-// Throughput path, three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy),
-// verify (the equations; register-bound) and the resolve pass over the items verify queued (normally the invalid
-// ones only; the grid is sized for the batch, lanes without a queue entry leave at once).  Small batches of the
-// fixed-generator schemes take the latency path instead.  The slot has been chosen by the caller (pick_slot).
-int launch_key_decode_per_item(const verify_params& P, const wire_keys& W, const uint32_t* skip_flag, hipStream_t s) {
-    decode_params D{};
-    D.n_src = W.n_cols; D.n = P.n; D.bad = W.bad;
-    for (uint32_t c = 0; c < W.n_cols; ++c) { D.src[c] = W.comp[c]; D.out[c] = W.out[c]; }
-    D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
-    D.skip_flag = skip_flag;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n)), dim3(BLOCK), 0, s, D);
+// ---- one verification call, in stages --------------------------------------------------------------------
+// A call is: begin (buffers, ordering against the slot's previous user, the key stream forked off), ingest (format
+// conversion of columns that have arrived: normalisation of extended points, decoding of the R points of a wire call),
+// keys (the key kernels, once every key column is in place), hash (challenge hashes and the other per-item preparation
+// of a range of items whose columns are all in place) and finish (the equations, the resolve pass).  A resident call
+// runs the stages once over all its items (launch_staged); a host-buffer call feeds them range by range while the
+// later ranges are still being uploaded, so that the keys of the whole call are counted and tabled ONCE and the
+// hashes start with the first bytes that arrive (run_host_block).
+//   throughput path, three launches per batch: prepare (hashes, scalar lattice, subgroup tests; high occupancy), verify
+//   (the equations; register-bound) and the resolve pass over the items verify queued (normally the invalid ones only);
+//   key-table path: the key kernels on the slot's key stream beside the hashes, then key_verify_kernel; whichever of
+//   verify_kernel / key_verify_kernel is not wanted leaves at once;  small batches take the latency path instead.
+enum : uint32_t { COLS_KEYS = 1, COLS_REST = 2, COLS_ALL = 3 };      // which columns of a range have just arrived
+struct staged_call {
+    verify_params P{};
+    bool wire = false;                // compressed points: W
+    wire_keys W{};
+    bool ext = false;                 // extended points: N[COLS_KEYS] the key columns, N[COLS_REST] the others, N[COLS_ALL] all
+    normalize_params N[4] = {};
+};
+struct verify_job {
+    staged_call C;
+    key_params K{}, Kd{};
+    key_decode_params KD{};
+    hipStream_t s = nullptr;          // the caller's stream: begin and finish are queued on it
+    hipStream_t side[HOST_SIDE_STREAMS] = {};   // further streams ranges were queued on (host-buffer calls), joined by finish
+    bool small = false, try_keys = false, split = false, forked = false, keys_queued = false, open = false;
+};
+
+int launch_normalize(normalize_params N, uint64_t first, uint64_t count, uint64_t n_call, hipStream_t s) {
+    if (!N.n_src || !count) return JJS_OK;
+    N.first = first; N.n = count;
+    size_t blocks = (count + BLOCK - 1) / BLOCK;
+    const size_t by_share = (count + (size_t)BLOCK * 32 - 1) / ((size_t)BLOCK * 32);
+    if (count == n_call) {
+        // a whole call: ~8 items per lane at BASELINE sizes (one inversion amortised over them), one item per lane for small calls
+        if (blocks > 512) blocks = 512;
+    } else {
+        // a range of a host-buffer call: ~8 items per lane from 2^18 items on (an inversion is 12 items' worth of products)
+        const size_t few = blocks < 64 ? blocks : 64, shared = (count + (size_t)BLOCK * 8 - 1) / ((size_t)BLOCK * 8);
+        blocks = few > shared ? few : shared;
+        if (blocks > 512) blocks = 512;
+    }
+    if (blocks < by_share) blocks = by_share;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, N);
     HIP_TRY(hipGetLastError());
     return JJS_OK;
 }
-int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) {
-    if (P.n == 0) return JJS_OK;
+int launch_key_decode_per_item(const verify_job& J, uint64_t first, uint64_t count, const uint32_t* skip_flag, hipStream_t s) {
+    const wire_keys& W = J.C.W;
+    decode_params D{};
+    D.n_src = W.n_cols; D.n = count; D.first = first; D.bad = W.bad;
+    for (uint32_t c = 0; c < W.n_cols; ++c) { D.src[c] = W.comp[c]; D.out[c] = W.out[c]; }
+    D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+    D.skip_flag = skip_flag;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, count)), dim3(BLOCK), 0, s, D);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+
+// The slot has been chosen by the caller (pick_slot) and holds the buffers the descriptor points at.
+int job_begin(verify_job& J, hipStream_t s) {
+    verify_params& P = J.C.P;
+    J.s = s;
 #if defined(JJS_PROFILING)
     P.skip_phases = g_skip_phases;
 #endif
@@ -878,101 +1139,175 @@ int launch_verify(verify_params P, hipStream_t s, const wire_keys* W = nullptr) 
     P.prep = sl->prep;
     P.workspace = sl->workspace;
     if (int rc = begin_shared(s)) return rc;
-    auto decode_signature_points = [&]() -> int {          // wire calls: R (R') of every item
-        decode_params D = W->sig;
-        D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
-        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n)), dim3(BLOCK), 0, s, D);
-        HIP_TRY(hipGetLastError());
-        return JJS_OK;
-    };
-    if (small_path_applies(P)) {
-        if (W) {
-            if (int rc = decode_signature_points()) return rc;
-            if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
-        }
-        if (int rc = launch_small(P, s)) return rc;
-        return end_shared(s);
-    }
+    J.open = true;
+    if (P.tally) HIP_TRY(hipMemsetAsync(P.tally, 0, 4 * sizeof(unsigned long long), s));
+    if (P.pre_malformed) HIP_TRY(hipMemsetAsync(const_cast<uint8_t*>(P.pre_malformed), 0, P.n, s));
+    J.small = small_path_applies(P);
+    if (J.small) { ++g->stats[JJS_PATH_LATENCY]; return JJS_OK; }
     if (int rc = ensure_pending(P.n)) return rc;
     P.pending_count = reinterpret_cast<unsigned long long*>(sl->pending);
     P.pending = sl->pending + 2;
     HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
-    key_params K{};
-    bool try_keys = key_path_applies(P);
-    // The keys are counted (and, for a wire call, decoded once each) on the key stream from the start, with the clearing
-    // of their tables, beside the first kernel of this stream.  With affine inputs that kernel is the challenge hashes,
-    // which do not wait for the decision (PREP_HEAD; PREP_TAIL later adds what only the throughput path needs); a wire
+    J.try_keys = key_path_applies(P);
+    if (!J.try_keys) { ++g->stats[JJS_PATH_THROUGHPUT]; return JJS_OK; }
+    // The keys are counted (and, for a wire call, decoded once each) on the slot's key stream, with the clearing of
+    // their tables, beside the first kernels of the caller's stream.  With affine or extended inputs those are the challenge
+    // hashes, which do not wait for the decision (PREP_HEAD; PREP_TAIL later adds what only the throughput path needs); a wire
     // call decodes the R points of its signatures meanwhile and hashes once its keys are in place.
-#if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
-    const bool fork_keys = false;
-#else
-    const bool fork_keys = try_keys;
-#endif
-    hipStream_t ks = fork_keys ? g->key_stream : s;          // where the keys are counted
-    if (fork_keys) {
-        HIP_TRY(hipEventRecord(g->key_fork, s));
-        HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
-    }
-    if (try_keys && setup_keys(P, K, ks) != JJS_OK) {
-        // no room for the key arena (it is sized for n / 16 keys per column): the batch simply takes the throughput
-        // path, as it would with keys that do not repeat
+    HIP_TRY(hipEventRecord(sl->key_fork, s));
+    HIP_TRY(hipStreamWaitEvent(sl->key_stream, sl->key_fork, 0));
+    J.forked = true;
+    if (setup_keys(P, J.K, sl->key_stream) != JJS_OK) {
+        // no room for the key tables: the batch simply takes the throughput path, as it would with keys that do not repeat
         (void)hipGetLastError();
-        try_keys = false;
+        J.try_keys = false;
+        ++g->stats[JJS_PATH_THROUGHPUT];
+        return JJS_OK;
     }
-    const bool split = fork_keys && try_keys && W == nullptr;
-    if (W)
-        if (int rc = decode_signature_points()) return rc;
-    if (try_keys) {
-        // key-table path: count the distinct keys, decide on the device, build the per-key tables beside the
-        // challenge hashes (key_stream); whichever of verify_kernel / key_verify_kernel is not wanted leaves at once
-        const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
-        key_params Kd = K;                       // a wire call deduplicates the 32-byte encodings
-        if (W)
-            for (uint32_t c = 0; c < K.n_cols; ++c) { Kd.col[c].src = W->comp[c]; Kd.col[c].key_bytes = 32; }
-        hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
-        hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
-        hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, Kd);
-        if (!fork_keys) {
-            HIP_TRY(hipEventRecord(g->key_fork, s));
-            HIP_TRY(hipStreamWaitEvent(g->key_stream, g->key_fork, 0));
-        }
-        const unsigned key_blocks = (K.n_cols * K.max_keys + BLOCK - 1) / BLOCK;
-        if (W) {
-            // one square root per distinct key on the key stream; this stream decodes the key columns item by item only
-            // if the batch turned the key tables down; then every item fetches its key's point
-            key_decode_params D{};
-            for (uint32_t c = 0; c < K.n_cols; ++c) D.out[c] = W->out[c];
-            D.bad = W->bad;
-            D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
-            hipLaunchKernelGGL(key_decode_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, Kd, D);
-            HIP_TRY(hipEventRecord(g->key_mid, g->key_stream));
-            HIP_TRY(hipStreamWaitEvent(s, g->key_mid, 0));               // the decision and the decoded keys
-            if (int rc = launch_key_decode_per_item(P, *W, K.counters + 2, s)) return rc;
-            hipLaunchKernelGGL(key_unpack_kernel, dim3(item_blocks), dim3(BLOCK), 0, s, Kd, D);
-        }
-        hipLaunchKernelGGL(key_count_kernel, dim3(item_blocks), dim3(BLOCK), 0, g->key_stream, K);
-        hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(1024), 0, g->key_stream, K);
-        hipLaunchKernelGGL(key_scatter_kernel, dim3(item_blocks), dim3(BLOCK), 0, g->key_stream, K);
-        hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, g->key_stream, K);
-        hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
-                           dim3(BLOCK), 0, g->key_stream, K);
-        HIP_TRY(hipEventRecord(g->key_join, g->key_stream));
-        P.key_flag = K.counters + 2;
-    } else if (W) {
-        if (int rc = launch_key_decode_per_item(P, *W, nullptr, s)) return rc;
+    P.key_flag = J.K.counters + 2;
+#if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
+    J.split = false;
+#else
+    J.split = !J.C.wire;
+#endif
+    return JJS_OK;
+}
+
+// format conversion of the columns `cols` of the items [first, first + count), which are now in device memory
+int job_ingest(verify_job& J, uint64_t first, uint64_t count, uint32_t cols, hipStream_t cs) {
+    if (!count) return JJS_OK;
+    if (J.C.ext)
+        if (int rc = launch_normalize(J.C.N[cols & 3u], first, count, J.C.P.n, cs)) return rc;
+    if (J.C.wire && (cols & COLS_REST)) {              // R (R') of every item
+        decode_params D = J.C.W.sig;
+        D.first = first; D.n = count;
+        D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+        hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, count)), dim3(BLOCK), 0, cs, D);
+        HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P, split ? (int)PREP_HEAD : (int)PREP_ALL);
-    if (try_keys) {
-        HIP_TRY(hipStreamWaitEvent(s, g->key_join, 0));
-        if (split) hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P, (int)PREP_TAIL);
-        hipLaunchKernelGGL(key_verify_kernel, dim3(grid_for(g->grid_key_verify, P.n)), dim3(BLOCK), 0, s, P, K);
+    return JJS_OK;
+}
+
+// Every key column of the call is in place (on the key stream's timeline: the caller has made it wait for whatever
+// put them there): count the distinct keys, decide on the device, build the per-key tables.
+int job_keys(verify_job& J) {
+    if (!J.try_keys) return JJS_OK;
+    const verify_params& P = J.C.P;
+    key_params& K = J.K;
+    hipStream_t ks = sl->key_stream;
+    const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
+    J.Kd = K;                                   // a wire call deduplicates the 32-byte encodings
+    if (J.C.wire)
+        for (uint32_t c = 0; c < K.n_cols; ++c) { J.Kd.col[c].src = J.C.W.comp[c]; J.Kd.col[c].key_bytes = 32; }
+    hipLaunchKernelGGL(key_dedup_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, J.Kd);
+    hipLaunchKernelGGL(key_assign_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, J.Kd);
+    hipLaunchKernelGGL(key_spread_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, J.Kd);
+    const unsigned key_blocks = (K.n_cols * K.max_keys + BLOCK - 1) / BLOCK;
+    if (J.C.wire) {
+        // one square root per distinct key; the items fetch their key's point in job_hash
+        for (uint32_t c = 0; c < K.n_cols; ++c) J.KD.out[c] = J.C.W.out[c];
+        J.KD.bad = J.C.W.bad;
+        J.KD.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+        hipLaunchKernelGGL(key_decode_kernel, dim3(key_blocks), dim3(BLOCK), 0, ks, J.Kd, J.KD);
+        HIP_TRY(hipEventRecord(sl->key_mid, ks));              // the decision and the decoded keys
+    }
+    hipLaunchKernelGGL(key_count_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, K);
+    hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(1024), 0, ks, K);
+    hipLaunchKernelGGL(key_scatter_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, K);
+    hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, ks, K);
+    hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, ks, K);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl->key_join, ks));
+    J.keys_queued = true;
+    return JJS_OK;
+}
+// a wire call that tries the key tables can hash only after job_keys (it waits for the decoded keys)
+bool job_hash_needs_keys(const verify_job& J) { return J.C.wire && J.try_keys; }
+
+// The items [first, first + count) have all their columns in place and ingested: hash them.
+int job_hash(verify_job& J, uint64_t first, uint64_t count, hipStream_t cs) {
+    if (!count) return JJS_OK;
+    const verify_params& P = J.C.P;
+    if (J.small) {
+        if (first != 0 || count != P.n) return fail(JJS_ERR_ARG, "internal: the latency path takes the call whole");
+        if (J.C.wire)
+            if (int rc = launch_key_decode_per_item(J, 0, P.n, nullptr, cs)) return rc;
+        return launch_small(P, cs);
+    }
+    if (J.C.wire) {
+        if (J.try_keys) {
+            if (!J.keys_queued) return fail(JJS_ERR_ARG, "internal: wire hashes before the key kernels");
+            HIP_TRY(hipStreamWaitEvent(cs, sl->key_mid, 0));
+            // this stream decodes the key columns item by item only if the batch turned the key tables down; else every
+            // item fetches its key's point
+            if (int rc = launch_key_decode_per_item(J, first, count, J.K.counters + 2, cs)) return rc;
+            hipLaunchKernelGGL(key_unpack_kernel, dim3((unsigned)grid_for(8192, count)), dim3(BLOCK), 0, cs, J.Kd, J.KD, first, count);
+        } else if (int rc = launch_key_decode_per_item(J, first, count, nullptr, cs)) return rc;
+    }
+    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, count)), dim3(BLOCK), 0, cs, P, J.split ? (int)PREP_HEAD : (int)PREP_ALL,
+                       first, count);
+    HIP_TRY(hipGetLastError());
+    return JJS_OK;
+}
+
+int job_finish(verify_job& J) {
+    const verify_params& P = J.C.P;
+    hipStream_t s = J.s;
+    for (hipStream_t& side : J.side) {              // ranges were queued on other streams: they join here
+        if (!side) continue;
+        HIP_TRY(hipEventRecord(g->side_join, side));
+        HIP_TRY(hipStreamWaitEvent(s, g->side_join, 0));
+        side = nullptr;
+    }
+    if (J.small) { J.open = false; return end_shared(s); }
+    if (J.try_keys) {
+        if (!J.keys_queued) return fail(JJS_ERR_ARG, "internal: finish before the key kernels");
+        HIP_TRY(hipStreamWaitEvent(s, sl->key_join, 0));
+        J.forked = false;
+        if (J.split) hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(g->grid_prepare, P.n)), dim3(BLOCK), 0, s, P, (int)PREP_TAIL, (uint64_t)0, P.n);
+        hipLaunchKernelGGL(key_verify_kernel, dim3(grid_for(g->grid_key_verify, P.n)), dim3(BLOCK), 0, s, P, J.K);
     }
     hipLaunchKernelGGL(verify_kernel, dim3(grid_for(sl->grid_verify, P.n)), dim3(BLOCK), 0, s, P);
     hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(g->grid_resolve, P.n * P.resolve_lanes)), dim3(BLOCK), 0, s, P);
     HIP_TRY(hipGetLastError());
+    if (J.try_keys) {
+        // what the keys of this call looked like, for the slot's next call (note_key_feedback); nobody waits for it
+        HIP_TRY(hipMemcpyAsync(sl->seen->counters, J.K.counters, sizeof(sl->seen->counters), hipMemcpyDeviceToHost, s));
+        sl->seen_pending = true; sl->seen_n = P.n; sl->seen_cols = J.K.n_cols;
+    }
+    J.open = false;
     return end_shared(s);
 }
+// A stage failed: whatever has been queued on the key stream or the second stream still uses the slot's buffers, so
+// the caller's stream joins both and the slot's event covers them (the error itself goes back to the caller).
+void job_abandon(verify_job& J) {
+    if (!J.open) return;
+    (void)hipGetLastError();
+    if (J.forked && hipEventRecord(sl->key_join, sl->key_stream) == hipSuccess) (void)hipStreamWaitEvent(J.s, sl->key_join, 0);
+    for (hipStream_t side : J.side)
+        if (side && hipEventRecord(g->side_join, side) == hipSuccess) (void)hipStreamWaitEvent(J.s, g->side_join, 0);
+    (void)hipEventRecord(sl->last_use, J.s);
+    J.open = false;
+}
 
+// A resident call: every stage once, over all items, in the order that puts the key kernels in front of the hashes.
+int launch_staged(const staged_call& C, hipStream_t s) {
+    if (C.P.n == 0) return JJS_OK;
+    verify_job J;
+    J.C = C;
+    int rc = job_begin(J, s);
+    if (!rc) rc = job_ingest(J, 0, C.P.n, COLS_ALL, s);
+    if (!rc && J.forked && C.ext) {                 // the key kernels read normalised key columns
+        rc = hipEventRecord(g->ingest_done, s) == hipSuccess && hipStreamWaitEvent(sl->key_stream, g->ingest_done, 0) == hipSuccess
+                 ? JJS_OK : fail(JJS_ERR_HIP, "event between the caller's stream and the key stream");
+    }
+    if (!rc) rc = job_keys(J);
+    if (!rc) rc = job_hash(J, 0, C.P.n, s);
+    if (!rc) rc = job_finish(J);
+    if (rc) job_abandon(J);
+    return rc;
+}
 // Every entry point works on the calling thread's current HIP device, which must be one jjs_init set up.
 int check_ready() {
     if (L.devs.empty()) return fail(JJS_ERR_NOT_INIT, "jjs_init has not been called");
@@ -989,31 +1324,23 @@ bool all_ok(Ptrs... p) {
     return ((p != nullptr && aligned16(p)) && ...);
 }
 
-extern bool g_keep_tally;
-int verify_dev_common(verify_params P, void* status, void* tally, hipStream_t s, const wire_keys* W = nullptr) {
-    if (status && !aligned16(status)) return fail(JJS_ERR_ARG, "status must be 16-byte aligned");
-    if (tally && !g_keep_tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
-    return launch_verify(P, s, W);
-}
-
 int init_device(device_state& d, int ordinal) {
     d.device = ordinal;
     HIP_TRY(hipSetDevice(ordinal));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
+    for (hipStream_t& side : d.side) HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d.host_begin, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
     {   // the per-key kernels are few, long waves that must finish before the challenge hashes do: dispatch them first
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&d.key_stream, hipStreamNonBlocking, hi));
+        d.key_priority = hi;
     }
-    HIP_TRY(hipEventCreateWithFlags(&d.key_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&d.key_mid, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&d.key_join, hipEventDisableTiming));
-    for (int i = 0; i < 33; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&d.side_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.ingest_done, hipEventDisableTiming));
+    for (size_t i = 0; i < HOST_MAX_PIECES; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_up[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_done[i], hipEventDisableTiming));
     }
@@ -1051,6 +1378,14 @@ int init_device(device_state& d, int ordinal) {
         HIP_TRY(hipMalloc(&c.workspace, lanes * WS_WORDS_PER_LANE * sizeof(uint32_t)));
         HIP_TRY(hipEventCreateWithFlags(&c.last_use, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c.last_use, d.stream));
+        if (i == 0 || i > N_SMALL_SLOTS) {       // slots whose calls can be large enough for the key tables: a key stream each
+            HIP_TRY(hipStreamCreateWithPriority(&c.key_stream, hipStreamNonBlocking, d.key_priority));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_mid, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_join, hipEventDisableTiming));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.seen), sizeof(key_feedback), hipHostMallocDefault));
+            memset(c.seen, 0, sizeof(key_feedback));
+        }
     }
     HIP_TRY(hipMalloc(&d.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
@@ -1079,24 +1414,28 @@ void free_device(device_state& d) {
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (call_slot& c : d.slots) {
-        void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small, c.keys};
+        if (c.key_stream) { (void)hipStreamSynchronize(c.key_stream); (void)hipStreamDestroy(c.key_stream); }
+        void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small, c.keys, c.key_pool};
         for (void* b : sb)
             if (b) (void)hipFree(b);
-        if (c.last_use) (void)hipEventDestroy(c.last_use);
+        if (c.seen) (void)hipHostFree(c.seen);
+        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
     }
     if (d.pinned) (void)hipHostFree(d.pinned);
     if (d.last_use) (void)hipEventDestroy(d.last_use);
-    for (int i = 0; i < 33; ++i) {
+    for (size_t i = 0; i < HOST_MAX_PIECES; ++i) {
         if (d.chunk_up[i]) (void)hipEventDestroy(d.chunk_up[i]);
         if (d.chunk_done[i]) (void)hipEventDestroy(d.chunk_done[i]);
     }
     if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
-    if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
+    for (hipStream_t side : d.side)
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (d.host_begin) (void)hipEventDestroy(d.host_begin);
-    if (d.key_stream) { (void)hipStreamSynchronize(d.key_stream); (void)hipStreamDestroy(d.key_stream); }
-    if (d.key_fork) (void)hipEventDestroy(d.key_fork);
-    if (d.key_mid) (void)hipEventDestroy(d.key_mid);
-    if (d.key_join) (void)hipEventDestroy(d.key_join);
+    if (d.side_join) (void)hipEventDestroy(d.side_join);
+    if (d.ingest_done) (void)hipEventDestroy(d.ingest_done);
+    delete d.stagers;
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = device_state{};
 }
@@ -1173,28 +1512,51 @@ struct device_restore {   // puts the calling thread back on the device it came 
 // Host-buffer calls.  The batch is cut into one contiguous block of ceil(n / devices) items per driven
 // device (the rule of jubjub_schnorr_amd/sharding.py) and every block is driven by its OWN host thread, so that
 // the uploads of different devices overlap (one thread issuing pageable copies for all devices would stage them
-// one after the other).  A block runs as a pipeline of chunks: the thread copies chunk c from the caller's (pageable)
-// arrays into one of two pinned staging slots -- with the help of a few more threads, a single one moves ~11 GB/s --
-// and queues its upload on the device's copy stream while chunk c-1 is being verified on the compute stream and the
-// statuses of chunk c-2 travel back into a pinned buffer.  The first chunk is small, because its upload is exposed;
-// every later one is HOST_CHUNK_GROWTH times its predecessor (the upload of a chunk takes about half as long per item
-// as the verification of the one before, and every chunk pays ~1 ms of its own), up to HOST_CHUNK_ITEMS_MAX.  Device arena, pinned staging and events are per device and only grow.  The
-// tallies accumulate over the chunks and are summed over the devices with one RCCL all-reduce at the end.
-// A failing block drains both of its streams before it reports, so nothing is in flight into the caller's or
-// the library's buffers when the call returns an error.
-struct host_col { const uint8_t* p; size_t width; };
-#ifndef JJS_HOST_CHUNK_LOG2_FIRST        // build-time knobs of the A/B runs recorded in DESIGN.md 6
-#define JJS_HOST_CHUNK_LOG2_FIRST 16
-#define JJS_HOST_CHUNK_LOG2_MAX 19
-#define JJS_HOST_CHUNK_GROWTH 4
+// one after the other).  A block is ONE verification call on its device (verify_job), fed piece by piece: the thread
+// copies a piece of the caller's (pageable) arrays into one of two pinned staging slots -- with the help of the device's
+// staging threads, a single one moves ~11 GB/s -- queues its upload on the device's copy stream and, behind the upload,
+// whatever the piece makes possible: format conversion of its columns, the key kernels once every key has arrived, the
+// challenge hashes of the items whose columns are now complete.  The pieces of a block that may take the key tables come
+// in this order: all columns of a first few items (so that the hashes start at once), then the KEY columns of all the
+// others (the keys of the whole call are counted and tabled once, beside the hashes), then the remaining columns in
+// growing ranges.  The equations run once at the end, over the whole block, as in a resident call.  Device arena, pinned
+// staging and events are per device and only grow.  The tallies are summed over the devices with one RCCL all-reduce.
+// A failing block drains its streams before it reports, so nothing is in flight into the caller's or the library's
+// buffers when the call returns an error.
+struct host_col { const uint8_t* p; size_t width; bool key; };
+// build-time knobs of the A/B runs recorded in DESIGN.md 6 (scripts/host_ab.sh)
+#ifndef JJS_HOST_LEAD_LOG2
+#define JJS_HOST_LEAD_LOG2 16            // items of the first piece (all columns) ...
 #endif
-constexpr size_t HOST_CHUNK_ITEMS_FIRST = size_t(1) << JJS_HOST_CHUNK_LOG2_FIRST, HOST_CHUNK_ITEMS_MAX = size_t(1) << JJS_HOST_CHUNK_LOG2_MAX,
-                 HOST_CHUNK_GROWTH = JJS_HOST_CHUNK_GROWTH;
-constexpr size_t HOST_MAX_CHUNKS = 32;
-constexpr unsigned HOST_STAGING_THREADS_MAX = 8;
-constexpr size_t HOST_STAGING_MIN_BYTES = size_t(4) << 20;     // below this a chunk is copied by the calling thread alone
-
-bool g_keep_tally = false;   // set while run_host issues the chunks of one batch: the counters accumulate
+#ifndef JJS_HOST_LEAD_SHARE_DEN
+#define JJS_HOST_LEAD_SHARE_NUM 1        // ... more of them, each twice its predecessor, while they stay within NUM/DEN of the block
+#define JJS_HOST_LEAD_SHARE_DEN 2
+#endif
+#ifndef JJS_HOST_REST_LOG2_FIRST
+#define JJS_HOST_REST_LOG2_FIRST 17      // items of the first range of remaining columns ...
+#endif
+#ifndef JJS_HOST_REST_GROWTH
+#define JJS_HOST_REST_GROWTH 2           // ... each later one this many times its predecessor ...
+#endif
+#ifndef JJS_HOST_REST_LOG2_MAX
+#define JJS_HOST_REST_LOG2_MAX 18        // ... up to this many
+#endif
+#ifndef JJS_HOST_KEYS_LOG2_MAX
+#define JJS_HOST_KEYS_LOG2_MAX 19        // the largest piece of key columns
+#endif
+constexpr size_t HOST_LEAD_ITEMS = size_t(1) << JJS_HOST_LEAD_LOG2, HOST_LEAD_SHARE_NUM = JJS_HOST_LEAD_SHARE_NUM, HOST_LEAD_SHARE_DEN = JJS_HOST_LEAD_SHARE_DEN,
+                 HOST_REST_ITEMS_FIRST = size_t(1) << JJS_HOST_REST_LOG2_FIRST, HOST_REST_GROWTH = JJS_HOST_REST_GROWTH,
+                 HOST_REST_ITEMS_MAX = size_t(1) << JJS_HOST_REST_LOG2_MAX, HOST_KEYS_ITEMS_MAX = size_t(1) << JJS_HOST_KEYS_LOG2_MAX;
+// pinned staging slots of a block.  Three, so that the staging copy of piece i + 2 can run while piece i is on the bus and
+// piece i + 1 waits for it (eight threads stage at about the speed of the bus: with two slots they took turns).
+// A piece travels as one copy per column: a single copy into a landing area, spread over the columns by a kernel, was
+// built and measured slower -- that kernel waits up to 0.85 ms for a wave slot once the hashes fill the chip.
+constexpr size_t HOST_SLOTS = 3;
+#ifndef JJS_HOST_STAGING_THREADS
+#define JJS_HOST_STAGING_THREADS 8
+#endif
+constexpr unsigned HOST_STAGING_THREADS_MAX = JJS_HOST_STAGING_THREADS;
+constexpr size_t HOST_STAGING_MIN_BYTES = size_t(4) << 20;     // below this a piece is copied by the calling thread alone
 
 int ensure_stage(size_t bytes) {
     if (bytes <= g->stage_bytes) return JJS_OK;
@@ -1218,126 +1580,284 @@ int ensure_pinned(size_t bytes) {
     g->pinned_bytes = bytes;
     return JJS_OK;
 }
-size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
 
-template <size_t K>
+struct host_piece {
+    size_t first, count;
+    uint32_t cols;             // COLS_KEYS, COLS_REST or COLS_ALL
+};
 struct host_block {
-    size_t lo = 0, hi = 0, chunks = 0, largest = 0;
-    size_t start[HOST_MAX_CHUNKS + 1] = {};      // chunk c covers items [start[c], start[c + 1]) of the block
+    size_t lo = 0, hi = 0;
+    std::vector<host_piece> pieces;
+    size_t largest_bytes = 0;  // of a piece in the pinned staging slots
     unsigned staging_threads = 1;
     int rc = JJS_OK;
     char err[512] = "";
     unsigned long long tally[4] = {0, 0, 0, 0};
 };
 
+// The upload order of a block of nl items.  row_keys / row_rest: bytes per item of the two column groups.
+//   * a block that cannot take the key tables: every column of growing ranges of items;
+//   * else the key columns travel ahead of the others, but only for the second half of the block.  The bus delivers a
+//     2^20-item single batch in 3.7 ms and the chip hashes it in 5.7: whatever is uploaded ahead of complete items leaves
+//     the hashes without input for that long (scripts/host_timeline.sh; keys of the whole block first: the chip idles from
+//     1.0 to 2.3 ms), while the per-key tables need ~3.8 ms from the moment the last key has arrived (the doubling chains are
+//     latency-bound) and are wanted when the hashes end.  So: all columns of 2^16, 2^17, 2^18 ... items while that stays
+//     within half the block, then the key columns of the rest, then its remaining columns in ranges of 2^17, 2^18, 2^18 ...
+//     items (ranges of equal size keep the staging copy of the next range shorter than the upload of this one);
+//   * a wire call hashes nothing before its keys are decoded (keys_gate_hashes): its key column goes first, whole.
+void plan_pieces(host_block& b, size_t nl, size_t row_keys, size_t row_rest, bool keys_gate_hashes) {
+    b.pieces.clear();
+    b.largest_bytes = 256;
+    auto add = [&](size_t first, size_t count, uint32_t cols) {
+        if (!count) return;
+        b.pieces.push_back(host_piece{first, count, cols});
+        const size_t bytes = count * ((cols & COLS_KEYS ? row_keys : 0) + (cols & COLS_REST ? row_rest : 0));
+        if (bytes > b.largest_bytes) b.largest_bytes = bytes;
+    };
+    // ranges: `first_len`, then times `growth` up to `cap`; a remainder of less than half a first range joins the range before it
+    auto ranges = [&](size_t from, size_t first_len, size_t growth, size_t cap, uint32_t cols) {
+        size_t pos = from, next = first_len < cap ? first_len : cap;
+        while (pos < nl) {
+            size_t len = next < nl - pos ? next : nl - pos;
+            if (nl - pos - len < first_len / 2) len = nl - pos;
+            add(pos, len, cols);
+            pos += len;
+            next = next * growth < cap ? next * growth : cap;
+        }
+    };
+    // very large blocks: larger pieces, so that their number stays within the events a device has
+    size_t cap_keys = HOST_KEYS_ITEMS_MAX, cap_rest = HOST_REST_ITEMS_MAX;
+    if (nl > cap_keys * 10) cap_keys = ((nl + 9) / 10 + 255) & ~size_t(255);
+    if (nl > cap_rest * 20) cap_rest = ((nl + 19) / 20 + 255) & ~size_t(255);
+    const bool keys_first = row_keys != 0 && nl >= KT_MIN_ITEMS && nl > 2 * HOST_LEAD_ITEMS;
+    if (!keys_first) {
+        ranges(0, HOST_LEAD_ITEMS, 4, cap_rest, COLS_ALL);
+        return;
+    }
+    size_t lead = 0;
+    if (!keys_gate_hashes) {
+        size_t next = HOST_LEAD_ITEMS;
+        do {
+            add(lead, next, COLS_ALL);
+            lead += next;
+            next = next * 2 < cap_rest ? next * 2 : cap_rest;
+        } while (lead + next <= nl / HOST_LEAD_SHARE_DEN * HOST_LEAD_SHARE_NUM);
+    }
+    ranges(lead, cap_keys, 1, cap_keys, COLS_KEYS);
+    ranges(lead, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, COLS_REST);
+}
+
+struct stage_task {          // one piece's pageable -> pinned copy, cut into T slices of every column
+    const host_col* cols; size_t n_cols;
+    size_t lo, first, count;
+    uint32_t group;
+    uint8_t* dst;
+    unsigned T;
+};
+// pageable -> pinned with streaming stores: the pinned slot is written once and read by the DMA engine only, so the
+// lines need not be fetched before they are written nor kept in the cache afterwards (memcpy does both for copies of this
+// size per thread).  dst 32-byte aligned; falls back to memcpy on a host without AVX2.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(JJS_HOST_NO_STREAM_COPY)
+__attribute__((target("avx2"))) void stream_copy_avx2(uint8_t* dst, const uint8_t* src, size_t bytes) {
+    size_t i = 0;
+    for (; i + 128 <= bytes; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < bytes) memcpy(dst + i, src + i, bytes - i);
+}
+void stream_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0 && bytes >= 4096) stream_copy_avx2(dst, src, bytes);
+    else memcpy(dst, src, bytes);
+}
+#else
+void stream_copy(uint8_t* dst, const uint8_t* src, size_t bytes) { memcpy(dst, src, bytes); }
+#endif
+void stage_slice(void* ctx, unsigned t) {
+    const stage_task& S = *static_cast<const stage_task*>(ctx);
+    const size_t i0 = S.count * t / S.T, i1 = S.count * (t + 1) / S.T;
+    uint8_t* q = S.dst;
+    for (size_t k = 0; k < S.n_cols; ++k) {
+        if (!((S.cols[k].key ? COLS_KEYS : COLS_REST) & S.group)) continue;
+        const size_t w = S.cols[k].width;
+        stream_copy(q + i0 * w, S.cols[k].p + (S.lo + S.first + i0) * w, (i1 - i0) * w);
+        q += S.count * w;
+    }
+}
+
+// Builds the call of one block from its device arrays (cols[k] of the block at dev[k]; nl items; statuses to st,
+// counters to tl): what the *_locked functions below do for a resident call, minus the launch.
+typedef int (*call_builder)(const void* const* dev, size_t nl, void* st, void* tl, hipStream_t s, staged_call& out);
+
 // The pipeline of one device's block; runs on the calling thread (one device) or on a thread of its own.
-template <size_t K, typename Launch>
-int run_host_block(device_state* dev, const host_col (&cols)[K], host_block<K>& b, uint8_t* status, Launch& launch) {
+int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_block& b, uint8_t* status, call_builder build,
+                   verify_job& J) {
     g = dev;
     HIP_TRY(hipSetDevice(g->device));
     const size_t nl = b.hi - b.lo;
-    // device arena: one array per column for the whole block, then the statuses
-    size_t bytes = 0, row = 0;
-    for (size_t k = 0; k < K; ++k) { bytes += pad256(nl * cols[k].width); row += cols[k].width; }
+    if (!nl) {                                           // an empty block still reports (zero) counters
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
+        HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
+        HIP_TRY(hipEventRecord(g->last_use, g->stream));
+        return JJS_OK;
+    }
+    // device arena: one array per column for the whole block, then the statuses;
+    // pinned staging: HOST_SLOTS slots of one piece each, then the statuses of the whole block
+    const size_t slot_bytes = pad256(b.largest_bytes);
+    size_t bytes = 0;
+    for (size_t k = 0; k < n_cols; ++k) bytes += pad256(nl * cols[k].width);
     bytes += pad256(nl);
-    if (int rc = ensure_stage(bytes ? bytes : 256)) return rc;
-    uint8_t* in[K];
+    if (int rc = ensure_stage(bytes)) return rc;
+    const void* in[8];
+    uint8_t* col_dev[8];
     uint8_t* p = g->stage;
-    for (size_t k = 0; k < K; ++k) { in[k] = p; p += pad256(nl * cols[k].width); }
+    for (size_t k = 0; k < n_cols; ++k) { in[k] = col_dev[k] = p; p += pad256(nl * cols[k].width); }
     uint8_t* st = p;
-    // pinned staging: two slots of one chunk of inputs each, then the statuses of the whole block
-    const size_t slot_bytes = pad256(b.largest * row);
-    if (int rc = ensure_pinned(2 * slot_bytes + pad256(nl) + 256)) return rc;
-    uint8_t* const slot[2] = {g->pinned, g->pinned + slot_bytes};
-    uint8_t* const pst = g->pinned + 2 * slot_bytes;
+    if (int rc = ensure_pinned(HOST_SLOTS * slot_bytes + pad256(nl) + 256)) return rc;
+    uint8_t* const pst = g->pinned + HOST_SLOTS * slot_bytes;
+    unsigned long long* const ptally = reinterpret_cast<unsigned long long*>(pst + pad256(nl));
+    if (!g->stagers && b.staging_threads > 1) g->stagers = new (std::nothrow) staging_pool(b.staging_threads - 1);
+    // The staging copy of piece i + 1 runs on the helper threads while this thread queues the uploads and the kernels of
+    // piece i (some 0.1 ms of HIP calls per piece, during which the bus would otherwise wait for the next piece).
+    stage_task tasks[HOST_SLOTS];
+    struct in_flight {          // the helpers read tasks[]: whatever way this function is left, they have finished first
+        staging_pool* pool = nullptr;
+        bool active = false;
+        ~in_flight() { if (active && pool) pool->join(); }
+    } staging;
+    staging.pool = g->stagers;
+    auto stage_begin = [&](size_t i) -> int {
+        const host_piece& pc = b.pieces[i];
+        if (i >= HOST_SLOTS) HIP_TRY(hipEventSynchronize(g->chunk_up[i - HOST_SLOTS]));      // the slot's previous upload has left it
+        size_t piece_bytes = 0;
+        for (size_t k = 0; k < n_cols; ++k)
+            if ((cols[k].key ? COLS_KEYS : COLS_REST) & pc.cols) piece_bytes += pc.count * cols[k].width;
+        stage_task& S = tasks[i % HOST_SLOTS];
+        S = stage_task{cols, n_cols, b.lo, pc.first, pc.count, pc.cols, g->pinned + (i % HOST_SLOTS) * slot_bytes, 1};
+        const unsigned threads = g->stagers ? g->stagers->helpers() + 1 : 1u;
+        // slices of about a megabyte, so that whoever is free (helpers, and this thread once it has queued the piece
+        // before) takes the next one
+        size_t slices = piece_bytes / (size_t(1) << 20);
+        if (slices > 4 * (size_t)threads) slices = 4 * (size_t)threads;
+        S.T = (piece_bytes >= HOST_STAGING_MIN_BYTES && threads > 1 && slices > 1) ? (unsigned)slices : 1u;
+        if (S.T > 1) { g->stagers->begin(S.T, stage_slice, &S); staging.active = true; }
+        return JJS_OK;
+    };
+    auto stage_finish = [&](size_t i) {
+        stage_task& S = tasks[i % HOST_SLOTS];
+        if (S.T > 1) { g->stagers->join(); staging.active = false; } else stage_slice(&S, 0);
+    };
+    const size_t np = b.pieces.size();
+    if (np > HOST_MAX_PIECES) return fail(JJS_ERR_ARG, "internal: %zu pieces", np);
+    if (int rc = stage_begin(0)) return rc;          // ... and of the first piece while this thread sets the call up
     // the arena and the counters may still be in use by the previous call's last launches
     HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
     HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
-    HIP_TRY(hipMemsetAsync(g->tally, 0, 4 * sizeof(unsigned long long), g->stream));
-    // successive chunks are verified on two streams in turn (and sit in different call slots), so that the
-    // latency-bound stretches of one chunk are filled with the arithmetic of the next
+    if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
+    if (int rc = job_begin(J, g->stream)) return rc;
+    // The ranges of the block are queued on several streams in turn: a launch waits for every block of its predecessor on
+    // the same stream, and a block of hashes lives for 1.4 ms, so on one stream (or two: scripts/host_timeline.sh) the chip
+    // runs half empty at the end of every range; with a stream per range in flight, whichever range has arrived fills the
+    // wave slots that come free.  The other streams start behind this one's job_begin (cleared flags and counters).
     HIP_TRY(hipEventRecord(g->host_begin, g->stream));
-    HIP_TRY(hipStreamWaitEvent(g->stream2, g->host_begin, 0));
-    hipStream_t const compute[2] = {g->stream, g->stream2};
+    hipStream_t compute[1 + HOST_SIDE_STREAMS] = {g->stream};
+    for (int k = 0; k < HOST_SIDE_STREAMS; ++k) {
+        HIP_TRY(hipStreamWaitEvent(g->side[k], g->host_begin, 0));
+        compute[1 + k] = g->side[k];
+    }
+    constexpr size_t NCS = 1 + HOST_SIDE_STREAMS;
 #if defined(JJS_PROFILING)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     double t_stage = 0, t_wait = 0;
 #endif
-    for (size_t c = 0; c <= b.chunks; ++c) {
-        if (c < b.chunks) {
-            const size_t off = b.start[c], len = b.start[c + 1] - off;
+    size_t last_key_piece = np;                         // the piece whose arrival completes the key columns
+    for (size_t i = 0; i < np; ++i)
+        if (b.pieces[i].cols & COLS_KEYS) last_key_piece = i;
+    struct deferred { size_t first, count; hipStream_t cs; };
+    std::vector<deferred> waiting;                      // ranges whose hashes need the key kernels queued first (wire calls)
+    for (size_t i = 0; i < np; ++i) {
+        const host_piece& pc = b.pieces[i];
+        uint8_t* const hp = g->pinned + (i % HOST_SLOTS) * slot_bytes;
 #if defined(JJS_PROFILING)
-            const double t0 = now();
+        const double t0 = now();
 #endif
-            if (c >= 2) HIP_TRY(hipEventSynchronize(g->chunk_up[c - 2]));      // the slot's previous upload has left it
+        stage_finish(i);
 #if defined(JJS_PROFILING)
-            const double t1 = now();
-            t_wait += t1 - t0;
+        const double t1 = now();
+        t_stage += t1 - t0;
 #endif
-            const void* dp[K];
-            uint8_t* hp = slot[c & 1];
-            // pageable -> pinned: thread t of T copies the t-th slice of every column
-            const unsigned T = len * row >= HOST_STAGING_MIN_BYTES ? b.staging_threads : 1u;
-            auto stage = [&](unsigned t) {
-                const size_t i0 = len * t / T, i1 = len * (t + 1) / T;
-                uint8_t* q = hp;
-                for (size_t k = 0; k < K; ++k) {
-                    const size_t w = cols[k].width;
-                    memcpy(q + i0 * w, cols[k].p + (b.lo + off + i0) * w, (i1 - i0) * w);
-                    q += len * w;
-                }
-            };
-            {
-                std::vector<std::thread> helpers;
-                for (unsigned t = 1; t < T; ++t) helpers.emplace_back(stage, t);
-                stage(0);
-                for (std::thread& h : helpers) h.join();
-            }
+        if (i + 1 < np)
+            if (int rc = stage_begin(i + 1)) return rc;
 #if defined(JJS_PROFILING)
-            t_stage += now() - t1;
+        t_wait += now() - t1;
 #endif
-            for (size_t k = 0; k < K; ++k) {
+        {
+            uint8_t* q = hp;
+            for (size_t k = 0; k < n_cols; ++k) {
+                if (!((cols[k].key ? COLS_KEYS : COLS_REST) & pc.cols)) continue;
                 const size_t w = cols[k].width;
-                HIP_TRY(hipMemcpyAsync(in[k] + off * w, hp, len * w, hipMemcpyHostToDevice, g->copy_stream));
-                dp[k] = in[k] + off * w;
-                hp += len * w;
+                HIP_TRY(hipMemcpyAsync(col_dev[k] + pc.first * w, q, pc.count * w, hipMemcpyHostToDevice, g->copy_stream));
+                q += pc.count * w;
             }
-            HIP_TRY(hipEventRecord(g->chunk_up[c], g->copy_stream));
-            HIP_TRY(hipStreamWaitEvent(compute[c & 1], g->chunk_up[c], 0));
-            if (int rc = launch(dp, len, (void*)(st + off), (void*)g->tally, (void*)compute[c & 1])) return rc;
-            HIP_TRY(hipEventRecord(g->chunk_done[c], compute[c & 1]));
         }
-        if (c > 0 && status) {            // statuses of the previous chunk, behind this chunk's upload
-            const size_t off = b.start[c - 1], len = b.start[c] - off;
-            HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->chunk_done[c - 1], 0));
-            HIP_TRY(hipMemcpyAsync(pst + off, st + off, len, hipMemcpyDeviceToHost, g->copy_stream));
+        HIP_TRY(hipEventRecord(g->chunk_up[i], g->copy_stream));
+        hipStream_t cs = compute[i % NCS];
+        if (i % NCS) J.side[i % NCS - 1] = cs;
+        HIP_TRY(hipStreamWaitEvent(cs, g->chunk_up[i], 0));
+        if (int rc = job_ingest(J, pc.first, pc.count, pc.cols, cs)) return rc;
+        HIP_TRY(hipEventRecord(g->chunk_done[i], cs));
+        if (i == last_key_piece && J.try_keys) {
+            // every key column is on the device (and converted): the key kernels of the whole block, once
+            for (size_t j = 0; j <= i; ++j)
+                if (b.pieces[j].cols & COLS_KEYS) HIP_TRY(hipStreamWaitEvent(sl->key_stream, g->chunk_done[j], 0));
+            if (int rc = job_keys(J)) return rc;
+            for (const deferred& d : waiting)
+                if (int rc = job_hash(J, d.first, d.count, d.cs)) return rc;
+            waiting.clear();
+        }
+        if (pc.cols & COLS_REST) {
+            // the items of this piece are complete; their key columns may have been converted on the other stream
+            for (size_t j = 0; j < i; ++j) {
+                const host_piece& o = b.pieces[j];
+                if ((o.cols & COLS_KEYS) && compute[j % NCS] != cs && o.first < pc.first + pc.count && pc.first < o.first + o.count)
+                    HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[j], 0));
+            }
+            if (job_hash_needs_keys(J) && !J.keys_queued) waiting.push_back(deferred{pc.first, pc.count, cs});
+            else if (int rc = job_hash(J, pc.first, pc.count, cs)) return rc;
         }
     }
-    // the second stream joins the first: what follows on g->stream (tally all-reduce, download) sees every chunk
-    if (b.chunks) {
-        HIP_TRY(hipEventRecord(g->host_begin, g->stream2));
-        HIP_TRY(hipStreamWaitEvent(g->stream, g->host_begin, 0));
-    }
+    if (!waiting.empty()) return fail(JJS_ERR_ARG, "internal: ranges left waiting for the key kernels");
+    if (int rc = job_finish(J)) return rc;
+    if (status) HIP_TRY(hipMemcpyAsync(pst, st, nl, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(ptally, g->tally, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipEventRecord(g->last_use, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    HIP_TRY(hipStreamSynchronize(g->copy_stream));
-    if (status && nl) memcpy(status + b.lo, pst, nl);
+    if (status) memcpy(status + b.lo, pst, nl);
+    for (int k = 0; k < 4; ++k) b.tally[k] = ptally[k];
 #if defined(JJS_PROFILING)
-    g_host_timing[0] = t_stage; g_host_timing[1] = t_wait; g_host_timing[2] = now() - t_begin; g_host_timing[3] = (double)b.chunks;
+    g_host_timing[0] = t_stage; g_host_timing[1] = t_wait; g_host_timing[2] = now() - t_begin; g_host_timing[3] = (double)np;
 #endif
     return JJS_OK;
 }
 
-template <size_t K, typename Launch>
-int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tally[4], Launch&& launch) {
-    for (size_t k = 0; k < K; ++k)
+int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, bool keys_gate_hashes) {
+    if (n_cols > 8) return fail(JJS_ERR_ARG, "internal: too many columns");
+    for (size_t k = 0; k < n_cols; ++k)
         if (n && !cols[k].p) return fail(JJS_ERR_ARG, "null input pointer");
     std::vector<device_state*> targets;
     if (L.devs.size() == 1) targets.push_back(g); else targets = L.devs;
     const size_t nd = targets.size();
-    std::vector<host_block<K>> blocks(nd);
+    std::vector<host_block> blocks(nd);
     device_restore restore;
-    struct keep_tally_scope { keep_tally_scope() { g_keep_tally = true; } ~keep_tally_scope() { g_keep_tally = false; } } keep;
     const size_t per = (n + nd - 1) / nd;
     // staging helpers: the host cores this process may use, shared among the devices it drives
     unsigned staging_threads = 1;
@@ -1349,44 +1869,38 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
         if (staging_threads > HOST_STAGING_THREADS_MAX) staging_threads = HOST_STAGING_THREADS_MAX;
         if (staging_threads < 1) staging_threads = 1;
     }
+    size_t row_keys = 0, row_rest = 0;
+    for (size_t k = 0; k < n_cols; ++k) (cols[k].key ? row_keys : row_rest) += cols[k].width;
     for (size_t d = 0; d < nd; ++d) {
-        host_block<K>& b = blocks[d];
+        host_block& b = blocks[d];
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
-        const size_t nl = b.hi - b.lo;
-        // chunk sizes: FIRST, then times GROWTH up to MAX (raised when the block would need more than HOST_MAX_CHUNKS);
-        // a remainder of less than half a first chunk joins the chunk before it; small calls pin only what they use
-        size_t cap = HOST_CHUNK_ITEMS_MAX;
-        if (nl > cap * (HOST_MAX_CHUNKS - 4)) cap = ((nl + HOST_MAX_CHUNKS - 5) / (HOST_MAX_CHUNKS - 4) + 255) & ~size_t(255);
-        size_t pos = 0, next = HOST_CHUNK_ITEMS_FIRST;
-        b.chunks = 0; b.largest = 1;
-        while (pos < nl) {
-            size_t len = next < nl - pos ? next : nl - pos;
-            if (nl - pos - len < HOST_CHUNK_ITEMS_FIRST / 2) len = nl - pos;
-            b.start[b.chunks++] = pos;
-            pos += len;
-            if (len > b.largest) b.largest = len;
-            next = next * HOST_CHUNK_GROWTH < cap ? next * HOST_CHUNK_GROWTH : cap;
-        }
-        b.start[b.chunks] = nl;
+        plan_pieces(b, b.hi - b.lo, row_keys, row_rest, keys_gate_hashes);
         b.staging_threads = staging_threads;
     }
     auto work = [&](size_t d) {
-        host_block<K>& b = blocks[d];
-        b.rc = run_host_block(targets[d], cols, b, status, launch);
+        host_block& b = blocks[d];
+        verify_job J;
+        b.rc = run_host_block(targets[d], cols, n_cols, b, status, build, J);
         if (b.rc != JJS_OK) {
             // leave nothing in flight into the caller's arrays, the pinned slots or the counters
-            (void)hipStreamSynchronize(targets[d]->stream);
-            (void)hipStreamSynchronize(targets[d]->stream2);
-            (void)hipStreamSynchronize(targets[d]->copy_stream);
             snprintf(b.err, sizeof(b.err), "%s", t_err);
+            job_abandon(J);
+            (void)hipStreamSynchronize(targets[d]->stream);
+            for (hipStream_t side : targets[d]->side) (void)hipStreamSynchronize(side);
+            (void)hipStreamSynchronize(targets[d]->copy_stream);
         }
     };
     if (nd == 1) {
         work(0);
     } else {
+        // one thread per device; a thread that cannot be started is not fatal: its block runs on this thread afterwards
         std::vector<std::thread> threads;
-        for (size_t d = 0; d < nd; ++d) threads.emplace_back(work, d);
+        std::vector<size_t> here;
+        for (size_t d = 0; d < nd; ++d) {
+            try { threads.emplace_back(work, d); } catch (...) { here.push_back(d); }
+        }
+        for (size_t d : here) work(d);
         for (std::thread& t : threads) t.join();
     }
     g = targets[0];
@@ -1397,18 +1911,20 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
             for (size_t d = 0; d < nd; ++d) { (void)hipSetDevice(targets[d]->device); (void)hipStreamSynchronize(targets[d]->stream); }
             return rc;
         }
-    for (size_t d = 0; d < nd; ++d) {
-        HIP_TRY(hipSetDevice(targets[d]->device));
-        HIP_TRY(hipMemcpyAsync(blocks[d].tally, targets[d]->tally, sizeof(blocks[d].tally), hipMemcpyDeviceToHost, targets[d]->stream));
-        HIP_TRY(hipEventRecord(targets[d]->last_use, targets[d]->stream));
+    if (nd > 1 && L.comms_up) {                // every device now holds the sum: fetch it again
+        for (size_t d = 0; d < nd; ++d) {
+            HIP_TRY(hipSetDevice(targets[d]->device));
+            HIP_TRY(hipMemcpyAsync(blocks[d].tally, targets[d]->tally, sizeof(blocks[d].tally), hipMemcpyDeviceToHost, targets[d]->stream));
+            HIP_TRY(hipEventRecord(targets[d]->last_use, targets[d]->stream));
+        }
+        int rc = JJS_OK;
+        for (size_t d = 0; d < nd; ++d) {          // drain every device even if one of them reports an error
+            hipError_t e = hipSetDevice(targets[d]->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(targets[d]->stream);
+            if (e != hipSuccess && rc == JJS_OK) rc = fail(JJS_ERR_HIP, "device %d: %s", targets[d]->device, hipGetErrorString(e));
+        }
+        if (rc != JJS_OK) return rc;
     }
-    int rc = JJS_OK;
-    for (size_t d = 0; d < nd; ++d) {          // drain every device even if one of them reports an error
-        hipError_t e = hipSetDevice(targets[d]->device);
-        if (e == hipSuccess) e = hipStreamSynchronize(targets[d]->stream);
-        if (e != hipSuccess && rc == JJS_OK) rc = fail(JJS_ERR_HIP, "device %d: %s", targets[d]->device, hipGetErrorString(e));
-    }
-    if (rc != JJS_OK) return rc;
     if (tally) {
         for (int i = 0; i < 4; ++i) tally[i] = blocks[0].tally[i];
         // test mode (logical devices sharing one GPU cannot form an RCCL clique): add the counters here
@@ -1423,7 +1939,7 @@ int run_host(const host_col (&cols)[K], size_t n, uint8_t* status, uint64_t tall
 
 extern "C" {
 
-int jjs_abi_version(void) { return 3; }
+int jjs_abi_version(void) { return 4; }
 const char* jjs_last_error(void) { return t_err; }
 
 int jjs_init(int device_count) {
@@ -1481,79 +1997,10 @@ int jjs_stream_sync(void* stream) {
     return JJS_OK;
 }
 
-// ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
-static int affine_single_locked(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
-                                void* stream) {
-    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n, (hipStream_t)stream);
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    return verify_dev_common(params_single((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)m, n,
-                                           g->comb_g, o), status, tally, (hipStream_t)stream);
-}
-static int affine_double_locked(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
-                                size_t n, void* status, void* tally, void* stream) {
-    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n, (hipStream_t)stream);
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    return verify_dev_common(params_double((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)Rp, (const uint8_t*)PK,
-                                           (const uint8_t*)PKp, (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o),
-                             status, tally, (hipStream_t)stream);
-}
-static int affine_vargen_locked(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
-                                void* status, void* tally, void* stream) {
-    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    pick_slot(n, (hipStream_t)stream);
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    return verify_dev_common(params_vargen((const uint8_t*)u, (const uint8_t*)R, (const uint8_t*)PK, (const uint8_t*)Gen,
-                                           (const uint8_t*)m, n, o), status, tally, (hipStream_t)stream);
-}
-int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
-                          void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return affine_single_locked(u, R, PK, m, n, status, tally, stream);
-}
-int jjs_verify_double_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
-                          size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return affine_double_locked(u, R, Rp, PK, PKp, m, n, status, tally, stream);
-}
-int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
-                          void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return affine_vargen_locked(u, R, PK, Gen, m, n, status, tally, stream);
-}
-int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
-                      uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return affine_single_locked(d[0], d[1], d[2], d[3], nl, st, tl, s);
-    });
-}
-int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
-                      const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 64}, {Rp, 64}, {PK, 64}, {PKp, 64}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return affine_double_locked(d[0], d[1], d[2], d[3], d[4], d[5], nl, st, tl, s);
-    });
-}
-int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
-                      size_t n, uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 64}, {PK, 64}, {Gen, 64}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return affine_vargen_locked(d[0], d[1], d[2], d[3], d[4], nl, st, tl, s);
-    });
-}
-
-// ---- wire formats: on-device decoding, then the same verify kernel -----------------------------------
+// ---- the staged_call of every scheme and input format --------------------------------------------------------------
+// A builder picks the call slot, sizes what the format needs in it and fills in the descriptors from the device arrays
+// d[0..] (in the order of the entry point's arguments).  Resident calls launch it at once (launch_staged), host-buffer
+// calls feed it piece by piece (run_host_block).
 static int ensure_wire(size_t n) {
     if (n <= sl->wire_items) return JJS_OK;
     if (sl->wire) {
@@ -1562,13 +2009,276 @@ static int ensure_wire(size_t n) {
         sl->wire = nullptr; sl->wire_items = 0;
     }
     size_t cap = n < 4096 ? 4096 : n;
-    HIP_TRY(hipMalloc(&sl->wire, cap * (4 * 64 + 16 + 48)));
+    HIP_TRY(hipMalloc(&sl->wire, cap * (4 * 64 + 16 + 2 * 48)));
     sl->wire_items = cap;
     return JJS_OK;
 }
 static uint8_t* wire_pts(int k) { return sl->wire + (size_t)k * sl->wire_items * 64; }
 static uint8_t* wire_bad() { return sl->wire + (size_t)4 * sl->wire_items * 64; }
-static uint32_t* wire_scratch() { return reinterpret_cast<uint32_t*>(sl->wire + (size_t)sl->wire_items * (4 * 64 + 16)); }
+// prefix products of the normalisation (normalize.h): one area for the key columns and one for the others, whose
+// launches may overlap in a host-buffer call
+static uint32_t* wire_scratch(int k) { return reinterpret_cast<uint32_t*>(sl->wire + (size_t)sl->wire_items * (4 * 64 + 16 + 48 * k)); }
+
+static int build_affine_single(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_single((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2], (const uint8_t*)d[3], n, g->comb_g, o);
+    return JJS_OK;
+}
+static int build_affine_double(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3], d[4], d[5])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_double((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2], (const uint8_t*)d[3], (const uint8_t*)d[4],
+                        (const uint8_t*)d[5], n, g->tag, g->comb_g, g->comb_gn, o);
+    return JJS_OK;
+}
+static int build_affine_vargen(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3], d[4])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_vargen((const uint8_t*)d[0], (const uint8_t*)d[1], (const uint8_t*)d[2], (const uint8_t*)d[3], (const uint8_t*)d[4], n, o);
+    return JJS_OK;
+}
+
+// wire formats: d = sig, pk, m.  The R points are decoded per item into wire_pts(0) (1), the keys per key or per item
+// (job_keys / job_hash) into the columns behind them; the flags of rejected encodings are P.pre_malformed.
+static int wire_common(staged_call& C, const void* sig, uint32_t sig_stride, uint32_t n_r, size_t n) {
+    decode_params D{};
+    D.n_src = n_r; D.n = n; D.bad = wire_bad();
+    for (uint32_t k = 0; k < n_r; ++k) { D.src[k] = fe_src{(const uint8_t*)sig, sig_stride, 32 + 32 * k}; D.out[k] = wire_pts((int)k); }
+    C.wire = true;
+    C.W.sig = D;
+    C.W.bad = wire_bad();
+    C.P.u = fe_src{(const uint8_t*)sig, sig_stride, 0};
+    C.P.pre_malformed = wire_bad();
+    C.P.decoded_points = 1;
+    return JJS_OK;
+}
+static int build_wire_single(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_single((const uint8_t*)d[0], wire_pts(0), wire_pts(1), (const uint8_t*)d[2], n, g->comb_g, o);
+    C.W.n_cols = 1;
+    C.W.comp[0] = fe_src{(const uint8_t*)d[1], 32, 0};  C.W.out[0] = wire_pts(1);      // PK
+    return wire_common(C, d[0], 64, 1, n);
+}
+static int build_wire_double(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_double((const uint8_t*)d[0], wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3), (const uint8_t*)d[2], n, g->tag,
+                        g->comb_g, g->comb_gn, o);
+    C.W.n_cols = 2;
+    C.W.comp[0] = fe_src{(const uint8_t*)d[1], 64, 0};  C.W.out[0] = wire_pts(2);      // PK
+    C.W.comp[1] = fe_src{(const uint8_t*)d[1], 64, 32}; C.W.out[1] = wire_pts(3);      // PK'
+    return wire_common(C, d[0], 96, 2, n);
+}
+static int build_wire_vargen(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_vargen((const uint8_t*)d[0], wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)d[2], n, o);
+    C.W.n_cols = 2;
+    C.W.comp[0] = fe_src{(const uint8_t*)d[1], 64, 0};  C.W.out[0] = wire_pts(1);      // PK
+    C.W.comp[1] = fe_src{(const uint8_t*)d[1], 64, 32}; C.W.out[1] = wire_pts(2);      // generator
+    return wire_common(C, d[0], 64, 1, n);
+}
+
+// extended coordinates (U, V, Z): normalised on the device into wire_pts(k), then the affine descriptors.  `keys`: bit k
+// set when point column k is a key column (they arrive, and are normalised, ahead of the others in a host-buffer call).
+static void ext_common(staged_call& C, const void* const* pts, uint32_t n_pts, uint32_t keys) {
+    C.ext = true;
+    for (uint32_t grp = COLS_KEYS; grp <= COLS_ALL; ++grp) {
+        normalize_params& N = C.N[grp];
+        N = normalize_params{};
+        for (uint32_t k = 0; k < n_pts; ++k) {
+            const bool is_key = ((keys >> k) & 1u) != 0;
+            if (!((is_key ? COLS_KEYS : COLS_REST) & grp)) continue;
+            N.src[N.n_src] = fe_src{(const uint8_t*)pts[k], 96, 0};
+            N.out[N.n_src] = wire_pts((int)k);
+            ++N.n_src;
+        }
+        N.bad = wire_bad();
+        N.scratch = wire_scratch(grp == COLS_KEYS ? 1 : 0);
+    }
+    C.P.pre_malformed = wire_bad();
+}
+static int build_ext_single(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_single((const uint8_t*)d[0], wire_pts(0), wire_pts(1), (const uint8_t*)d[3], n, g->comb_g, o);
+    const void* pts[] = {d[1], d[2]};                      // R, PK
+    ext_common(C, pts, 2, 2u);
+    return JJS_OK;
+}
+static int build_ext_double(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3], d[4], d[5])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_double((const uint8_t*)d[0], wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3), (const uint8_t*)d[5], n, g->tag,
+                        g->comb_g, g->comb_gn, o);
+    const void* pts[] = {d[1], d[2], d[3], d[4]};          // R, R', PK, PK'
+    ext_common(C, pts, 4, 12u);
+    return JJS_OK;
+}
+static int build_ext_vargen(const void* const* d, size_t n, void* status, void* tally, hipStream_t s, staged_call& C) {
+    if (n && !all_ok(d[0], d[1], d[2], d[3], d[4])) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
+    pick_slot(n, s);
+    if (int rc = ensure_wire(n)) return rc;
+    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
+    C = staged_call{};
+    C.P = params_vargen((const uint8_t*)d[0], wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)d[4], n, o);
+    const void* pts[] = {d[1], d[2], d[3]};                // R, PK, Gen
+    ext_common(C, pts, 3, 6u);
+    return JJS_OK;
+}
+
+// a resident call: device pointers d[], asynchronous on `stream`
+static int resident_call(call_builder build, const void* const* d, size_t n, void* status, void* tally, void* stream) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (status && !aligned16(status)) return fail(JJS_ERR_ARG, "status must be 16-byte aligned");
+    if (n == 0) {
+        if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(unsigned long long), s));
+        return JJS_OK;
+    }
+    staged_call C;
+    if (int rc = build(d, n, status, tally, s, C)) return rc;
+    return launch_staged(C, s);
+}
+// a host-buffer call: blocking
+static int host_call(call_builder build, const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4],
+                     bool keys_gate_hashes = false) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    return run_host(cols, n_cols, n, status, tally, build, keys_gate_hashes);
+}
+
+// ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
+int jjs_verify_single_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status,
+                          void* tally, void* stream) {
+    const void* d[] = {u, R, PK, m};
+    return resident_call(build_affine_single, d, n, status, tally, stream);
+}
+int jjs_verify_double_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                          size_t n, void* status, void* tally, void* stream) {
+    const void* d[] = {u, R, Rp, PK, PKp, m};
+    return resident_call(build_affine_double, d, n, status, tally, stream);
+}
+int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                          void* status, void* tally, void* stream) {
+    const void* d[] = {u, R, PK, Gen, m};
+    return resident_call(build_affine_vargen, d, n, status, tally, stream);
+}
+int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
+                      uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {PK, 64, true}, {m, 32, false}};
+    return host_call(build_affine_single, cols, 4, n, status, tally);
+}
+int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                      const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {Rp, 64, false}, {PK, 64, true}, {PKp, 64, true}, {m, 32, false}};
+    return host_call(build_affine_double, cols, 6, n, status, tally);
+}
+int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
+                      size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {PK, 64, true}, {Gen, 64, true}, {m, 32, false}};
+    return host_call(build_affine_vargen, cols, 5, n, status, tally);
+}
+
+// ---- wire formats: on-device decoding, then the same verify kernels -----------------------------------
+int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    const void* d[] = {sig, pk, m};
+    return resident_call(build_wire_single, d, n, status, tally, stream);
+}
+int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    const void* d[] = {sig, pk, m};
+    return resident_call(build_wire_double, d, n, status, tally, stream);
+}
+int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
+    const void* d[] = {sig, pk, m};
+    return resident_call(build_wire_vargen, d, n, status, tally, stream);
+}
+int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{sig, 64, false}, {pk, 32, true}, {m, 32, false}};
+    return host_call(build_wire_single, cols, 3, n, status, tally, true);
+}
+int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{sig, 96, false}, {pk, 64, true}, {m, 32, false}};
+    return host_call(build_wire_double, cols, 3, n, status, tally, true);
+}
+int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{sig, 64, false}, {pk, 64, true}, {m, 32, false}};
+    return host_call(build_wire_vargen, cols, 3, n, status, tally, true);
+}
+
+// ---- extended coordinates (U, V, Z): normalised on the device, then the same verify kernels -----------------
+int jjs_verify_single_ext_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
+                              void* stream) {
+    const void* d[] = {u, R, PK, m};
+    return resident_call(build_ext_single, d, n, status, tally, stream);
+}
+int jjs_verify_double_ext_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
+                              size_t n, void* status, void* tally, void* stream) {
+    const void* d[] = {u, R, Rp, PK, PKp, m};
+    return resident_call(build_ext_double, d, n, status, tally, stream);
+}
+int jjs_verify_vargen_ext_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
+                              void* status, void* tally, void* stream) {
+    const void* d[] = {u, R, PK, Gen, m};
+    return resident_call(build_ext_vargen, d, n, status, tally, stream);
+}
+int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n, uint8_t* status,
+                          uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {PK, 96, true}, {m, 32, false}};
+    return host_call(build_ext_single, cols, 4, n, status, tally);
+}
+int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
+                          const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {Rp, 96, false}, {PK, 96, true}, {PKp, 96, true}, {m, 32, false}};
+    return host_call(build_ext_double, cols, 6, n, status, tally);
+}
+int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m, size_t n,
+                          uint8_t* status, uint64_t tally[4]) {
+    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {PK, 96, true}, {Gen, 96, true}, {m, 32, false}};
+    return host_call(build_ext_vargen, cols, 5, n, status, tally);
+}
+
+// Which method the calls on the current device took (include/jjs_gpu.h).  Calls that tried the key tables are counted
+// when the library next looks at their slot (their decision is made on the device): after the stream has drained,
+// every finished call is in.
+int jjs_path_stats(uint64_t out[JJS_PATH_STATS]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (!out) return fail(JJS_ERR_ARG, "null pointer");
+    size_t pool = 0;
+    for (call_slot& c : g->slots) {
+        sl = &c;
+        if (c.key_stream) note_key_feedback();
+        pool += c.key_pool_bytes;
+    }
+    for (int i = 0; i < JJS_PATH_STATS; ++i) out[i] = g->stats[i];
+    out[JJS_PATH_KEY_POOL_BYTES] = pool;
+    return JJS_OK;
+}
 
 static int launch_decode(decode_params D, hipStream_t s) {
     D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
@@ -1578,236 +2288,6 @@ static int launch_decode(decode_params D, hipStream_t s) {
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, D);
     HIP_TRY(hipGetLastError());
     return end_shared(s);
-}
-
-static int wire_single_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                              void* stream) {
-    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
-    decode_params D{};
-    D.n_src = 1; D.n = n; D.bad = wire_bad();
-    D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    wire_keys W;                                                                 // everything is decoded by launch_verify
-    W.sig = D;
-    W.n_cols = 1; W.bad = wire_bad();
-    W.comp[0] = fe_src{(const uint8_t*)pk, 32, 0};  W.out[0] = wire_pts(1);      // PK
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_single((const uint8_t*)sig, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
-    P.u = fe_src{(const uint8_t*)sig, 64, 0};
-    P.pre_malformed = wire_bad();
-    P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s, &W);
-}
-static int wire_double_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                              void* stream) {
-    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
-    decode_params D{};
-    D.n_src = 2; D.n = n; D.bad = wire_bad();
-    D.src[0] = fe_src{(const uint8_t*)sig, 96, 32}; D.out[0] = wire_pts(0);      // R
-    D.src[1] = fe_src{(const uint8_t*)sig, 96, 64}; D.out[1] = wire_pts(1);      // R'
-    wire_keys W;
-    W.sig = D;
-    W.n_cols = 2; W.bad = wire_bad();
-    W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(2);      // PK
-    W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(3);      // PK'
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_double((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3),
-                                    (const uint8_t*)m, n, g->tag, g->comb_g, g->comb_gn, o);
-    P.u = fe_src{(const uint8_t*)sig, 96, 0};
-    P.pre_malformed = wire_bad();
-    P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s, &W);
-}
-static int wire_vargen_locked(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally,
-                              void* stream) {
-    if (n && !all_ok(sig, pk, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    HIP_TRY(hipMemsetAsync(wire_bad(), 0, n, s));
-    decode_params D{};
-    D.n_src = 1; D.n = n; D.bad = wire_bad();
-    D.src[0] = fe_src{(const uint8_t*)sig, 64, 32}; D.out[0] = wire_pts(0);      // R
-    wire_keys W;
-    W.sig = D;
-    W.n_cols = 2; W.bad = wire_bad();
-    W.comp[0] = fe_src{(const uint8_t*)pk, 64, 0};  W.out[0] = wire_pts(1);      // PK
-    W.comp[1] = fe_src{(const uint8_t*)pk, 64, 32}; W.out[1] = wire_pts(2);      // generator
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_vargen((const uint8_t*)sig, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
-    P.u = fe_src{(const uint8_t*)sig, 64, 0};
-    P.pre_malformed = wire_bad();
-    P.decoded_points = 1;
-    return verify_dev_common(P, status, tally, s, &W);
-}
-typedef int (*wire_fn)(const void*, const void*, const void*, size_t, void*, void*, void*);
-static int wire_host(wire_fn fn, const uint8_t* sig, size_t sig_w, const uint8_t* pk, size_t pk_w, const uint8_t* m, size_t n,
-                     uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{sig, sig_w}, {pk, pk_w}, {m, 32}};
-    return run_host(cols, n, status, tally, [fn](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return fn(d[0], d[1], d[2], nl, st, tl, s);
-    });
-}
-int jjs_verify_single_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return wire_single_locked(sig, pk, m, n, status, tally, stream);
-}
-int jjs_verify_double_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return wire_double_locked(sig, pk, m, n, status, tally, stream);
-}
-int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return wire_vargen_locked(sig, pk, m, n, status, tally, stream);
-}
-int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    return wire_host(wire_single_locked, sig, 64, pk, 32, m, n, status, tally);
-}
-int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    return wire_host(wire_double_locked, sig, 96, pk, 64, m, n, status, tally);
-}
-int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    return wire_host(wire_vargen_locked, sig, 64, pk, 64, m, n, status, tally);
-}
-
-// ---- extended coordinates (U, V, Z): normalised on the device, then the same verify kernels -----------------
-static int launch_normalize(normalize_params N, hipStream_t s) {
-    N.bad = wire_bad();
-    N.scratch = wire_scratch();
-    // ~8 items per lane at BASELINE sizes (one inversion amortised over them), one item per lane for small calls
-    size_t blocks = (N.n + BLOCK - 1) / BLOCK, by_share = (N.n + (size_t)BLOCK * 32 - 1) / ((size_t)BLOCK * 32);
-    if (blocks > 512) blocks = 512;
-    if (blocks < by_share) blocks = by_share;
-    HIP_TRY(hipMemsetAsync(wire_bad(), 0, N.n, s));
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, N);
-    HIP_TRY(hipGetLastError());
-    return JJS_OK;
-}
-static fe_src ext_src(const void* p) { return fe_src{(const uint8_t*)p, 96, 0}; }
-
-static int ext_single_locked(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
-                             void* stream) {
-    if (n && !all_ok(u, R, PK, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    normalize_params N{};
-    N.n_src = 2; N.n = n;
-    N.src[0] = ext_src(R);  N.out[0] = wire_pts(0);
-    N.src[1] = ext_src(PK); N.out[1] = wire_pts(1);
-    if (int rc = launch_normalize(N, s)) return rc;
-    if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_single((const uint8_t*)u, wire_pts(0), wire_pts(1), (const uint8_t*)m, n, g->comb_g, o);
-    P.pre_malformed = wire_bad();
-    return verify_dev_common(P, status, tally, s);
-}
-static int ext_double_locked(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
-                             size_t n, void* status, void* tally, void* stream) {
-    if (n && !all_ok(u, R, Rp, PK, PKp, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    normalize_params N{};
-    N.n_src = 4; N.n = n;
-    N.src[0] = ext_src(R);   N.out[0] = wire_pts(0);
-    N.src[1] = ext_src(Rp);  N.out[1] = wire_pts(1);
-    N.src[2] = ext_src(PK);  N.out[2] = wire_pts(2);
-    N.src[3] = ext_src(PKp); N.out[3] = wire_pts(3);
-    if (int rc = launch_normalize(N, s)) return rc;
-    if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_double((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), wire_pts(3), (const uint8_t*)m, n,
-                                    g->tag, g->comb_g, g->comb_gn, o);
-    P.pre_malformed = wire_bad();
-    return verify_dev_common(P, status, tally, s);
-}
-static int ext_vargen_locked(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n, void* status,
-                             void* tally, void* stream) {
-    if (n && !all_ok(u, R, PK, Gen, m)) return fail(JJS_ERR_ARG, "null or misaligned input pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { if (tally) HIP_TRY(hipMemsetAsync(tally, 0, 32, s)); return JJS_OK; }
-    pick_slot(n, (hipStream_t)stream);
-    if (int rc = ensure_wire(n)) return rc;
-    if (int rc = begin_shared(s)) return rc;
-    normalize_params N{};
-    N.n_src = 3; N.n = n;
-    N.src[0] = ext_src(R);   N.out[0] = wire_pts(0);
-    N.src[1] = ext_src(PK);  N.out[1] = wire_pts(1);
-    N.src[2] = ext_src(Gen); N.out[2] = wire_pts(2);
-    if (int rc = launch_normalize(N, s)) return rc;
-    if (int rc = end_shared(s)) return rc;
-    out_ptrs o{(uint8_t*)status, (unsigned long long*)tally, nullptr, sl->workspace};
-    verify_params P = params_vargen((const uint8_t*)u, wire_pts(0), wire_pts(1), wire_pts(2), (const uint8_t*)m, n, o);
-    P.pre_malformed = wire_bad();
-    return verify_dev_common(P, status, tally, s);
-}
-int jjs_verify_single_ext_dev(const void* u, const void* R, const void* PK, const void* m, size_t n, void* status, void* tally,
-                              void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return ext_single_locked(u, R, PK, m, n, status, tally, stream);
-}
-int jjs_verify_double_ext_dev(const void* u, const void* R, const void* Rp, const void* PK, const void* PKp, const void* m,
-                              size_t n, void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return ext_double_locked(u, R, Rp, PK, PKp, m, n, status, tally, stream);
-}
-int jjs_verify_vargen_ext_dev(const void* u, const void* R, const void* PK, const void* Gen, const void* m, size_t n,
-                              void* status, void* tally, void* stream) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    return ext_vargen_locked(u, R, PK, Gen, m, n, status, tally, stream);
-}
-int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n, uint8_t* status,
-                          uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 96}, {PK, 96}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return ext_single_locked(d[0], d[1], d[2], d[3], nl, st, tl, s);
-    });
-}
-int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
-                          const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 96}, {Rp, 96}, {PK, 96}, {PKp, 96}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return ext_double_locked(d[0], d[1], d[2], d[3], d[4], d[5], nl, st, tl, s);
-    });
-}
-int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m, size_t n,
-                          uint8_t* status, uint64_t tally[4]) {
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
-    const host_col cols[] = {{u, 32}, {R, 96}, {PK, 96}, {Gen, 96}, {m, 32}};
-    return run_host(cols, n, status, tally, [](const void* const* d, size_t nl, void* st, void* tl, void* s) {
-        return ext_vargen_locked(d[0], d[1], d[2], d[3], d[4], nl, st, tl, s);
-    });
 }
 
 int jjs_decompress_dev(const void* in, size_t n, void* affine_out, void* ok_out, void* stream) {
@@ -2046,6 +2526,16 @@ int jjs_debug_force_path(int which) {
 int jjs_debug_host_timing(double out[4]) {
     std::lock_guard<std::mutex> lock(L.mu);
     for (int i = 0; i < 4; ++i) out[i] = g_host_timing[i];
+    return JJS_OK;
+}
+int jjs_debug_pin_hash_seed(int on) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    g_pin_hash_seed = on != 0;
+    return JJS_OK;
+}
+int jjs_debug_fail_key_arena(int on) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    g_fail_key_arena = on != 0;
     return JJS_OK;
 }
 int jjs_debug_allow_virtual_devices(int allow) {

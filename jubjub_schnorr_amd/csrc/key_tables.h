@@ -51,16 +51,19 @@ constexpr uint32_t KT_MIN_MULTIPLICITY = 16;     // the tables pay from ~6 signa
 constexpr uint32_t KT_MAX_PROBES = 128;          // hash-table probes per key before the batch gives up on key tables
 constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
-// arena words per column for a batch of n items: narrow windows for up to n / KT_MIN_MULTIPLICITY keys, wide ones for up
-// to n / KT_WIDE_MULTIPLICITY
+// The bases and tables of the keys live in a pool that is sized by the number of distinct keys the slot's calls have
+// carried, not by the batch size (jjs_gpu.hip setup_keys): a pool column holds `narrow` keys with narrow windows or `wide`
+// keys with wide ones, and these are the words its two regions need for that.
 JJS_HD constexpr size_t kt_max(size_t a, size_t b) { return a > b ? a : b; }
-JJS_HD constexpr size_t kt_base_words_for(size_t n) {
-    return kt_max((n / KT_MIN_MULTIPLICITY) * kt_positions(KT_WINDOW_NARROW), (n / KT_WIDE_MULTIPLICITY) * kt_positions(KT_WINDOW_WIDE)) * KT_BASE_WORDS;
+JJS_HD constexpr size_t kt_base_words_for_keys(size_t narrow, size_t wide) {
+    return kt_max(narrow * kt_positions(KT_WINDOW_NARROW), wide * kt_positions(KT_WINDOW_WIDE)) * KT_BASE_WORDS;
 }
-JJS_HD constexpr size_t kt_table_words_for(size_t n) {
-    return kt_max((n / KT_MIN_MULTIPLICITY) * kt_positions(KT_WINDOW_NARROW) * kt_table_words(KT_WINDOW_NARROW),
-                  (n / KT_WIDE_MULTIPLICITY) * kt_positions(KT_WINDOW_WIDE) * kt_table_words(KT_WINDOW_WIDE));
+JJS_HD constexpr size_t kt_table_words_for_keys(size_t narrow, size_t wide) {
+    return kt_max(narrow * kt_positions(KT_WINDOW_NARROW) * kt_table_words(KT_WINDOW_NARROW),
+                  wide * kt_positions(KT_WINDOW_WIDE) * kt_table_words(KT_WINDOW_WIDE));
 }
+// bytes of bases + tables of one key
+JJS_HD constexpr size_t kt_key_bytes(int w) { return (size_t)kt_positions(w) * (KT_BASE_WORDS + kt_table_words(w)) * 4; }
 
 struct key_column {
     fe_src src;              // the key points: 64 B affine (u || v); during the dedup of a wire call the 32 B encodings
@@ -76,10 +79,16 @@ struct key_column {
     uint32_t* tables;        // [keys][positions][table words]: {0 .. 2^(w-1)} * base, cached-addend form
 };
 struct key_params {
-    uint32_t n_cols, max_keys;
+    uint32_t n_cols;
+    uint32_t max_keys;       // keys per column whose narrow-window tables fit the slot's table pool (also the bound of the ids
+                             // that get a representative item); max_keys_wide: the same for wide windows
+    uint32_t max_keys_wide;
+    uint32_t pad_;
+    uint64_t seed;           // per-call seed of the dedup hash (kt_hash)
     key_column col[2];
     uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 0 = throughput path, else the window width of
-                             // the key-table path; [3] a probe sequence overflowed
+                             // the key-table path; [3] a probe sequence overflowed; [4] the keys repeat but their tables do
+                             // not fit the pool (the host grows it for the next call)
     uint32_t force_window;   // profiling build only (0 in the product): KT_WINDOW_NARROW = never the wide windows
     uint32_t keep_order;     // profiling build only (0 in the product): the lanes take the items in the caller's order
     uint64_t n;
@@ -103,8 +112,10 @@ JJS_HD key_column kt_col(const key_params& K, int32_t idx) {
     return c;
 }
 
-JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item, uint32_t bytes) {
-    uint64_t h = 0x9e3779b97f4a7c15ull;
+// seed: drawn by the host for every call (key_params::seed), so that keys which share a probe sequence cannot be computed
+// ahead of time; the probe limit above stays as the backstop
+JJS_HD uint64_t kt_hash(const fe_src& src, uint64_t item, uint32_t bytes, uint64_t seed) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ seed;
 #pragma unroll
     for (uint32_t off = 0; off < 64; off += 32) {
         if (off >= bytes) break;

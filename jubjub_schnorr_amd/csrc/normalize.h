@@ -24,7 +24,8 @@ struct normalize_params {
     uint8_t* out[4];      // affine u || v, n x 64 each
     uint8_t* bad;         // n bytes, set to 1 when a coordinate of item i is not canonical
     uint32_t* scratch;    // 9 words per item: running prefix products
-    uint64_t n;
+    uint64_t n;           // items of this launch: first .. first + n - 1 (a host-buffer call normalises range by range)
+    uint64_t first;
 };
 
 JJS_HD bool words_are_zero(const words8& a) {
@@ -63,13 +64,13 @@ JJS_HD item_z load_item_z(const normalize_params& P, uint64_t item) {
     return r;
 }
 
-// All items of one lane: item = lane, lane + lanes, ...   (lanes = total number of lanes of the launch)
+// All items of one lane: item = first + lane, first + lane + lanes, ...   (lanes = total number of lanes of the launch)
 JJS_HD void normalize_lane(const normalize_params& P, uint64_t lane, uint64_t lanes) {
     if (lane >= P.n) return;
     const uint64_t count = (P.n - lane + lanes - 1) / lanes;
     fe_n acc = fe_n_one();
     for (uint64_t j = 0; j < count; ++j) {
-        const uint64_t item = lane + j * lanes;
+        const uint64_t item = P.first + lane + j * lanes;
         uint32_t* s = P.scratch + 9 * item;
 #pragma unroll
         for (int i = 0; i < 9; ++i) s[i] = acc.l[i];
@@ -77,7 +78,7 @@ JJS_HD void normalize_lane(const normalize_params& P, uint64_t lane, uint64_t la
     }
     fe_n inv = fq_inverse(acc);                       // never zero: zero Z were replaced by 1
     for (uint64_t j = count; j-- > 0;) {
-        const uint64_t item = lane + j * lanes;
+        const uint64_t item = P.first + lane + j * lanes;
         const item_z iz = load_item_z(P, item);
         fe_n pre;
         const uint32_t* s = P.scratch + 9 * item;

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r02}; SCHEMES=${2:-"single double vargen"};
 for S in $SCHEMES single_unique; do
   KEYS=""; U=0; SS=$S
   if [ "$S" = "single_unique" ]; then SS=single; KEYS="--keys 1048576"; U=1; fi
-  B="python3 $R/bench.py --scheme $SS $KEYS --no-cpu-baseline --no-two-streams"
+  B="python3 $R/bench.py --scheme $SS $KEYS --no-cpu-baseline --no-two-streams --no-host-buffers"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_${S}_trace -- $B --steps 5 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_trace.log 2>&1 &&
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${T}_${S}_fetch -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_fetch.log 2>&1 &&
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${T}_${S}_write -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_write.log 2>&1 &&

@@ -2,7 +2,7 @@
 # Kernel timeline of one 2^20-item batch (start / end of every kernel relative to the batch's first, with its stream):
 # what runs beside what.  Usage (through gpurun): bash scripts/timeline.sh <tag> [scheme] [extra bench flags] [label]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r02}; SCHEME=${2:-single}; X=${3:-}; S=${4:-$SCHEME}; cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/timeline_${T}_$S -- python3 $R/bench.py --scheme $SCHEME $X --no-cpu-baseline --no-two-streams --steps 3 --warmup 2 > $R/gpurun_out/timeline_${T}_$S.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/timeline_${T}_$S -- python3 $R/bench.py --scheme $SCHEME $X --no-cpu-baseline --no-two-streams --no-host-buffers --steps 3 --warmup 2 > $R/gpurun_out/timeline_${T}_$S.log 2>&1 || exit 1
 python3 - "$(find $R/gpurun_out/timeline_${T}_$S -name '*kernel_trace.csv' | head -1)" > $R/gpurun_out/timeline_${T}_$S.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -45,6 +45,34 @@ def main() -> None:
             assert (st.cpu().numpy() == want).all(), (scheme, path)
             assert tally.cpu().numpy().tolist() == [int((want == k).sum()) for k in range(4)], (scheme, path)
     lib.jjs_debug_force_path(0)
+    # a device that cannot hold the key-table pool: the same batches take the throughput path, statuses unchanged, and the
+    # path statistics say so (resident and host-buffer entry points)
+    for scheme in ("single", "double", "vargen"):
+        b = make_batch(scheme, 65536 + 37, seed=808, n_keys=300)
+        want = oracle_verify(scheme, b)
+        before = eng.path_stats()
+        assert lib.jjs_debug_fail_key_arena(1) == 0
+        st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
+        st_h, tally_h = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])
+        assert lib.jjs_debug_fail_key_arena(0) == 0
+        assert (st.cpu().numpy() == want).all() and (st_h == want).all(), scheme
+        assert tally.cpu().numpy().tolist() == tally_h.tolist() == [int((want == k).sum()) for k in range(4)], scheme
+        after = eng.path_stats()
+        assert after["throughput"] == before["throughput"] + 2, (before, after)
+        assert after["key_tables_wide"] + after["key_tables_narrow"] == before["key_tables_wide"] + before["key_tables_narrow"]
+    # keys crafted to collide in the dedup table: harmless under the per-call seed of the product; with the seed pinned
+    # (what the sender would need to know) the probe limit sends the batch down the throughput path, statuses unchanged
+    from helpers import crafted_collision_batch
+    b = crafted_collision_batch()
+    want = oracle_verify("single", b)
+    for pinned in (0, 1):
+        before = eng.path_stats()
+        assert lib.jjs_debug_pin_hash_seed(pinned) == 0
+        st, tally = eng.verify("single", *[dev(b[k]) for k in ARG_ORDER["single"]])
+        assert (st.cpu().numpy() == want).all(), pinned
+        after = eng.path_stats()
+        assert after["keys_probe_limit"] - before["keys_probe_limit"] == pinned, (pinned, before, after)
+    lib.jjs_debug_pin_hash_seed(0)
     print("FORCEPATH OK")
 
 

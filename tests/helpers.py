@@ -265,6 +265,27 @@ def to_extended(points: np.ndarray, rng: np.random.Generator, z_one_every: int =
     return out
 
 
+def ext_on_device(eng, points: np.ndarray, seed: int = 11) -> np.ndarray:
+    """to_extended for large arrays: U = u*Z, V = v*Z through the engine's field multiplier (itself pinned against the
+    oracle by test_fq_mul).  Rows with a non-canonical coordinate cannot be rescaled: they keep their bytes with Z = 1."""
+    import torch
+    n = len(points)
+    z = np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
+    z[:, 31] &= 0x3F; z[:, 0] |= 1
+    big = np.zeros(n, bool)
+    for half in (points[:, :32], points[:, 32:]):
+        for i in np.where(half[:, 31] >= 0x73)[0]:
+            big[i] = big[i] or to_int(half[i]) >= o.Q
+    z[big] = fe_bytes(1)
+    zd = torch.from_numpy(z).cuda()
+    cd = torch.from_numpy(np.ascontiguousarray(points)).cuda()
+    U = eng.debug_fq_mul(cd[:, :32].contiguous(), zd).cpu().numpy()
+    V = eng.debug_fq_mul(cd[:, 32:].contiguous(), zd).cpu().numpy()
+    out = np.concatenate([U, V, z], 1)
+    out[big, :64] = points[big]
+    return np.ascontiguousarray(out)
+
+
 def batch_to_extended(scheme: str, b: dict, seed: int = 3) -> list:
     """The arrays of a batch in ABI order with every point array turned into extended coordinates."""
     rng = np.random.default_rng(seed)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.jjs_abi_version() == 3
+    assert lib.jjs_abi_version() == 4
 
 
 def exported(path):
@@ -45,11 +45,12 @@ def test_product_library_has_no_bypass_switch():
     the -DJJS_PROFILING build, which declares them in include/jjs_gpu_profiling.h."""
     from jubjub_schnorr_amd import _ffi
     prof_syms = header_symbols("jjs_gpu_profiling.h")
-    assert prof_syms == ["jjs_debug_allow_virtual_devices", "jjs_debug_force_path", "jjs_debug_host_timing", "jjs_debug_skip_phases"] == sorted(_ffi.PROFILING_SIGNATURES)
+    assert prof_syms == ["jjs_debug_allow_virtual_devices", "jjs_debug_fail_key_arena", "jjs_debug_force_path", "jjs_debug_host_timing",
+                         "jjs_debug_pin_hash_seed", "jjs_debug_skip_phases"] == sorted(_ffi.PROFILING_SIGNATURES)
     product = exported(os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so"))
     for s in prof_syms:
         assert s not in product, s
-    assert not any("skip" in s or "virtual" in s or "force" in s for s in product if s.startswith("jjs_"))
+    assert not any("skip" in s or "virtual" in s or "force" in s or "fail" in s or "pin_" in s for s in product if s.startswith("jjs_"))
     # no string of the product binary names an environment switch
     blob = open(os.path.join(ROOT, "jubjub_schnorr_amd", "libjjs_gpu.so"), "rb").read()
     assert b"JJS_DEBUG" not in blob and b"JJS_GPU_LIB" not in blob

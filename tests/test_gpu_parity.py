@@ -8,7 +8,7 @@ import pytest
 
 import jjs_oracle as o
 import jjs_oracle_c as oc
-from helpers import (ARG_ORDER, batch_to_extended, edge_cases, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
+from helpers import (ARG_ORDER, batch_to_extended, edge_cases, ext_on_device, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
                      torsion_grid)
 
 pytestmark = pytest.mark.gpu
@@ -204,10 +204,11 @@ def test_gpu_signer_matches_oracle(eng, scheme):
         assert (host(a) == b).all()
 
 
-@pytest.mark.parametrize("scheme,log2n", [("single", 20), ("double", 20), ("vargen", 20)])
+@pytest.mark.parametrize("scheme,log2n", [("single", 20), ("double", 20), ("vargen", 20), ("single", 21)])
 def test_full_size_properties(eng, scheme, log2n):
     """BASELINE-size batch: inputs from the GPU signer, known corruption pattern, so the expected
-    status of every item is known by construction; plus an oracle check of a random sample."""
+    status of every item is known by construction; plus an oracle check of a random sample.  2^21 single signatures
+    are one GPU's shard of BASELINE.json configs[3] (2^24 over 8 GPUs)."""
     import torch
     n = 1 << log2n
     gen = torch.Generator(device="cpu").manual_seed(0x6A6A73 + log2n)
@@ -521,6 +522,26 @@ def test_key_table_path_against_oracle(eng, scheme):
     assert (got == want).all(), np.where(got != want)[0][:10]
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
     assert set(want.tolist()) == {0, 1, 2, 3}
+    # the blocking host-buffer entry points feed the same engine piece by piece (all columns of the first 2^16 items, then
+    # the key columns of all the others, then the rest: csrc/jjs_gpu.hip run_host_block): the batch three times over
+    # (3 x 2^17 items, so that every kind of piece occurs), affine and extended coordinates, same statuses
+    tiled = {k: np.concatenate([v, v, v]) for k, v in b.items()}
+    want3 = np.concatenate([want, want, want])
+    before = eng.path_stats()
+    st_h, tally_h = eng.verify(scheme, *[tiled[k] for k in ARG_ORDER[scheme]])
+    assert (st_h == want3).all(), np.where(st_h != want3)[0][:10]
+    assert tally_h.tolist() == [int((want3 == k).sum()) for k in range(4)]
+    st_h, tally_h = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])          # two pieces, every column in both
+    assert (st_h == want).all() and tally_h.tolist() == host(tally).tolist()
+    ext = [ext_on_device(eng, tiled[k]) if tiled[k].shape[1] == 64 else tiled[k] for k in ARG_ORDER[scheme]]
+    st_e, tally_e = eng.verify_ext(scheme, *ext)
+    assert (st_e == want3).all(), np.where(st_e != want3)[0][:10]
+    assert tally_e.tolist() == [int((want3 == k).sum()) for k in range(4)]
+    st_e, _ = eng.verify_ext(scheme, *[dev(a) for a in ext])
+    assert (host(st_e) == want3).all()
+    after = eng.path_stats()                              # all of these took the key tables (256+ signatures per key)
+    assert after["key_tables_wide"] - before["key_tables_wide"] == 4, (before, after)
+    assert after["throughput"] == before["throughput"] and after["keys_do_not_repeat"] == before["keys_do_not_repeat"]
     # the same items with every key made distinct in its bytes is impossible without re-signing; instead check the
     # fall-back decision: 2^16 items under 2^16 / 8 keys (8 per key: below the threshold) still verify the same
     m = 1 << 16
@@ -574,6 +595,13 @@ def test_key_table_path_wire_against_oracle(eng, scheme):
     assert (got == want).all(), np.where(got != want)[0][:10]
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
     assert set(want.tolist()) == {0, 1, 2, 3} and (want[negated] != 0).all()
+    # host buffers, the batch three times over: the key column travels first, the keys are decoded once for the whole call
+    want3 = np.concatenate([want, want, want])
+    st_h, tally_h = eng.verify_wire(scheme, *[np.concatenate([a, a, a]) for a in (sig, pk, m)])
+    assert (st_h == want3).all(), np.where(st_h != want3)[0][:10]
+    assert tally_h.tolist() == [int((want3 == k).sum()) for k in range(4)]
+    st_h, _ = eng.verify_wire(scheme, sig, pk, m)
+    assert (st_h == want).all()
     # below the key-table threshold (8 items per key) the keys are decoded item by item: same statuses
     sel = np.concatenate([np.arange(i, n, 512)[:8] for i in range(512)] * 16)[:1 << 16]
     st2, _ = eng.verify_wire(scheme, dev(sig[sel]), dev(pk[sel]), dev(m[sel]))
@@ -609,10 +637,44 @@ def test_key_table_decision_boundary(eng, n_keys):
     assert host(st[sel]).tolist() == oracle_verify("single", sample).tolist()
 
 
+def test_key_table_pool_grows_with_the_keys_it_sees(eng):
+    """2^20 single signatures under 32 768 keys (32 each: the key tables pay) need 4.1 GB of tables, more than the pool a
+    call slot starts with: the first call takes the throughput path and says so in the path statistics, the next call
+    finds the pool grown and takes the key tables; statuses identical (and right by construction) both times.  The
+    SURVEY workload (4 096 keys) before it leaves the pool at its initial size: memory follows the keys, not the batch."""
+    import torch
+    import bench
+    n = 1 << 20
+    arrays, expect = bench.make_inputs(eng, "single", n, 0)
+    call = [arrays[k] for k in ARG_ORDER["single"]]
+    s = torch.cuda.Stream()                  # a stream of its own: the call takes a big slot no earlier test has used this way
+    with torch.cuda.stream(s):
+        st, _ = eng.verify("single", *call)
+    s.synchronize()
+    assert torch.equal(st, expect)
+    small = eng.path_stats()
+    arrays, expect = bench.make_inputs(eng, "single", n, 0, n_keys=32768)
+    call = [arrays[k] for k in ARG_ORDER["single"]]
+    with torch.cuda.stream(s):
+        st1, t1 = eng.verify("single", *call)
+    s.synchronize()
+    mid = eng.path_stats()
+    with torch.cuda.stream(s):
+        st2, t2 = eng.verify("single", *call)
+    s.synchronize()
+    after = eng.path_stats()
+    assert torch.equal(st1, expect) and torch.equal(st2, expect) and torch.equal(t1, t2)
+    assert mid["keys_pool_too_small"] == small["keys_pool_too_small"] + 1, (small, mid)
+    assert after["key_tables_narrow"] == mid["key_tables_narrow"] + 1, (mid, after)
+    assert after["key_pool_bytes"] > mid["key_pool_bytes"] >= small["key_pool_bytes"] > 0
+    assert after["key_pool_bytes"] - mid["key_pool_bytes"] < 6 << 30
+
+
 def test_keys_crafted_to_collide_in_the_hash_table(eng):
-    """2 000 distinct public-key byte strings built to land on ONE slot of the engine's key hash table (the hash of
-    csrc/key_tables.h is public and unkeyed, so a sender can do this): the probe sequences are cut at KT_MAX_PROBES and
-    the batch takes the throughput path; the call stays fast and every status is still the oracle's."""
+    """2 000 distinct public-key byte strings built to land on ONE slot of the engine's key hash table as it would be
+    with a known seed.  The product draws a fresh seed per call, so here they are ordinary keys: the call stays fast and
+    every status is the oracle's.  tests/forcepath_child.py runs the same batch with the seed pinned (profiling build):
+    the probe sequences are then cut at KT_MAX_PROBES and the batch takes the throughput path."""
     from helpers import crafted_collision_batch
     b = crafted_collision_batch()
     want = oracle_verify("single", b)
