@@ -35,9 +35,12 @@ int jjs_debug_fail_key_arena(int on);
 /* on != 0: the dedup hash of the key tables runs with seed 0 instead of a fresh seed per call, so that a test can
  * present keys crafted to collide in it (what the seed keeps a sender from doing). */
 int jjs_debug_pin_hash_seed(int on);
-/* Where the last host-buffer call on one device spent its host time: out[0] seconds copying the caller's arrays into
- * the pinned slots, out[1] seconds waiting for a slot's previous upload, out[2] seconds in all, out[3] pieces. */
-int jjs_debug_host_timing(double out[4]);
+/* Where the last host-buffer call on one device spent its host time, in seconds: out[0] waiting for the staging copy
+ * of a piece to finish (it runs one piece ahead on helper threads), out[1] starting the next one (includes waiting for
+ * its pinned slot), out[2] the whole block, out[3] pieces, out[4] from the entry to the first upload being queued,
+ * out[5] until everything was queued, out[6] waiting for the device to drain after that, out[7] copying the statuses
+ * out. */
+int jjs_debug_host_timing(double out[8]);
 
 #ifdef __cplusplus
 }

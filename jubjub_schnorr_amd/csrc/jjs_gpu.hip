@@ -456,6 +456,7 @@ __global__ __launch_bounds__(BLOCK) void key_unpack_kernel(key_params K, key_dec
 // (U, V, Z) -> affine for the *_ext entry points: every lane owns the items lane, lane + lanes, ... and shares one
 // field inversion among them (normalize.h)
 __global__ __launch_bounds__(BLOCK) void normalize_kernel(normalize_params P) {
+    __builtin_amdgcn_s_setprio(3);            // few waves, a long dependent chain, and the hashes of their items wait for them
     normalize_lane(P, (uint64_t)blockIdx.x * BLOCK + threadIdx.x, (uint64_t)gridDim.x * BLOCK);
 }
 __global__ __launch_bounds__(BLOCK) void compress_kernel(const uint8_t* affine, uint64_t n, uint8_t* out) {
@@ -690,6 +691,7 @@ struct device_state {
     unsigned next_small = 0, next_medium = 0, next_big = 0;
     hipStream_t stream = nullptr;  // used by the host-buffer entry points
     hipStream_t side[HOST_SIDE_STREAMS] = {};   // ... whose ranges go to `stream` and these in turn (run_host_block)
+    hipStream_t ingest[2] = {};                 // ... and whose extended points are normalised here, ahead of the hashes (priority)
     hipEvent_t host_begin = nullptr;
     uint32_t* comb_g = nullptr;
     uint32_t* comb_gn = nullptr;
@@ -777,7 +779,7 @@ uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_pr
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
 int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
-double g_host_timing[4] = {0, 0, 0, 0};   // last host-buffer call: seconds staging, waiting for slots, total; chunks
+double g_host_timing[8] = {};     // last host-buffer call, seconds: see jjs_debug_host_timing (include/jjs_gpu_profiling.h)
 bool g_keep_order = false;        // ... 0x1000: key-table path without grouping the items by key
 int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
 bool g_fail_key_arena = false;    // set by jjs_debug_fail_key_arena: the key-table pool "cannot be allocated"
@@ -1340,6 +1342,7 @@ int init_device(device_state& d, int ordinal) {
     }
     HIP_TRY(hipEventCreateWithFlags(&d.side_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ingest_done, hipEventDisableTiming));
+    for (hipStream_t& is : d.ingest) HIP_TRY(hipStreamCreateWithPriority(&is, hipStreamNonBlocking, d.key_priority));
     for (size_t i = 0; i < HOST_MAX_PIECES; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_up[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d.chunk_done[i], hipEventDisableTiming));
@@ -1432,6 +1435,8 @@ void free_device(device_state& d) {
     if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
     for (hipStream_t side : d.side)
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    for (hipStream_t is : d.ingest)
+        if (is) { (void)hipStreamSynchronize(is); (void)hipStreamDestroy(is); }
     if (d.host_begin) (void)hipEventDestroy(d.host_begin);
     if (d.side_join) (void)hipEventDestroy(d.side_join);
     if (d.ingest_done) (void)hipEventDestroy(d.ingest_done);
@@ -1701,6 +1706,11 @@ typedef int (*call_builder)(const void* const* dev, size_t nl, void* st, void* t
 int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_block& b, uint8_t* status, call_builder build,
                    verify_job& J) {
     g = dev;
+#if defined(JJS_PROFILING)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_stage = 0, t_wait = 0, t_first = 0;
+#endif
     HIP_TRY(hipSetDevice(g->device));
     const size_t nl = b.hi - b.lo;
     if (!nl) {                                           // an empty block still reports (zero) counters
@@ -1774,11 +1784,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         compute[1 + k] = g->side[k];
     }
     constexpr size_t NCS = 1 + HOST_SIDE_STREAMS;
-#if defined(JJS_PROFILING)
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = now();
-    double t_stage = 0, t_wait = 0;
-#endif
+    hipStream_t converted_on[HOST_MAX_PIECES] = {};     // the stream a piece's columns were converted on (job_ingest)
     size_t last_key_piece = np;                         // the piece whose arrival completes the key columns
     for (size_t i = 0; i < np; ++i)
         if (b.pieces[i].cols & COLS_KEYS) last_key_piece = i;
@@ -1810,11 +1816,21 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
             }
         }
         HIP_TRY(hipEventRecord(g->chunk_up[i], g->copy_stream));
+#if defined(JJS_PROFILING)
+        if (i == 0) t_first = now() - t_begin;
+#endif
         hipStream_t cs = compute[i % NCS];
         if (i % NCS) J.side[i % NCS - 1] = cs;
-        HIP_TRY(hipStreamWaitEvent(cs, g->chunk_up[i], 0));
-        if (int rc = job_ingest(J, pc.first, pc.count, pc.cols, cs)) return rc;
-        HIP_TRY(hipEventRecord(g->chunk_done[i], cs));
+        // Extended points are normalised on a stream of higher priority than the hashes: that kernel is a few waves with a
+        // long dependent chain (one inversion per lane), its piece cannot be hashed before it ends, and behind the hashes of
+        // the pieces before it it waited 0.8-1.2 ms for wave slots instead of running 0.25 (scripts/host_timeline.sh).
+        hipStream_t is = J.C.ext ? g->ingest[i & 1] : cs;
+        converted_on[i] = is;
+        HIP_TRY(hipStreamWaitEvent(is, g->chunk_up[i], 0));
+        if (is != cs && i < 2) HIP_TRY(hipStreamWaitEvent(is, g->host_begin, 0));     // behind job_begin's cleared flags
+        if (int rc = job_ingest(J, pc.first, pc.count, pc.cols, is)) return rc;
+        HIP_TRY(hipEventRecord(g->chunk_done[i], is));
+        if (is != cs) HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[i], 0));
         if (i == last_key_piece && J.try_keys) {
             // every key column is on the device (and converted): the key kernels of the whole block, once
             for (size_t j = 0; j <= i; ++j)
@@ -1828,7 +1844,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
             // the items of this piece are complete; their key columns may have been converted on the other stream
             for (size_t j = 0; j < i; ++j) {
                 const host_piece& o = b.pieces[j];
-                if ((o.cols & COLS_KEYS) && compute[j % NCS] != cs && o.first < pc.first + pc.count && pc.first < o.first + o.count)
+                if ((o.cols & COLS_KEYS) && converted_on[j] != cs && o.first < pc.first + pc.count && pc.first < o.first + o.count)
                     HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[j], 0));
             }
             if (job_hash_needs_keys(J) && !J.keys_queued) waiting.push_back(deferred{pc.first, pc.count, cs});
@@ -1837,14 +1853,21 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     }
     if (!waiting.empty()) return fail(JJS_ERR_ARG, "internal: ranges left waiting for the key kernels");
     if (int rc = job_finish(J)) return rc;
+#if defined(JJS_PROFILING)
+    const double t_queued = now();
+#endif
     if (status) HIP_TRY(hipMemcpyAsync(pst, st, nl, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipMemcpyAsync(ptally, g->tally, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipEventRecord(g->last_use, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+#if defined(JJS_PROFILING)
+    const double t_drained = now();
+#endif
     if (status) memcpy(status + b.lo, pst, nl);
     for (int k = 0; k < 4; ++k) b.tally[k] = ptally[k];
 #if defined(JJS_PROFILING)
     g_host_timing[0] = t_stage; g_host_timing[1] = t_wait; g_host_timing[2] = now() - t_begin; g_host_timing[3] = (double)np;
+    g_host_timing[4] = t_first; g_host_timing[5] = t_queued - t_begin; g_host_timing[6] = t_drained - t_queued; g_host_timing[7] = now() - t_drained;
 #endif
     return JJS_OK;
 }
@@ -1888,6 +1911,7 @@ int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uin
             job_abandon(J);
             (void)hipStreamSynchronize(targets[d]->stream);
             for (hipStream_t side : targets[d]->side) (void)hipStreamSynchronize(side);
+            for (hipStream_t is : targets[d]->ingest) (void)hipStreamSynchronize(is);
             (void)hipStreamSynchronize(targets[d]->copy_stream);
         }
     };
@@ -2523,9 +2547,9 @@ int jjs_debug_force_path(int which) {
     g_force_window = ((which >> 8) & 15) == KT_WINDOW_NARROW ? ((which >> 8) & 15) : 0;   // 0x500: narrow key-table windows whatever the keys
     return JJS_OK;
 }
-int jjs_debug_host_timing(double out[4]) {
+int jjs_debug_host_timing(double out[8]) {
     std::lock_guard<std::mutex> lock(L.mu);
-    for (int i = 0; i < 4; ++i) out[i] = g_host_timing[i];
+    for (int i = 0; i < 8; ++i) out[i] = g_host_timing[i];
     return JJS_OK;
 }
 int jjs_debug_pin_hash_seed(int on) {

@@ -35,9 +35,11 @@ def main():
            "seconds": best, "verifications_per_s": (1 << log2n) / best}
     if timing:
         import ctypes
-        t = (ctypes.c_double * 4)()
+        t = (ctypes.c_double * 8)()
         _ffi.check(_ffi.lib().jjs_debug_host_timing(t), "host_timing")
-        rec["last_call"] = {"staging_copy_s": t[0], "waiting_for_slot_s": t[1], "total_s": t[2], "chunks": int(t[3])}
+        rec["last_call_ms"] = {"waiting_for_staging": round(t[0] * 1e3, 3), "starting_next_staging": round(t[1] * 1e3, 3),
+                               "total": round(t[2] * 1e3, 3), "pieces": int(t[3]), "until_first_upload_queued": round(t[4] * 1e3, 3),
+                               "until_all_queued": round(t[5] * 1e3, 3), "draining": round(t[6] * 1e3, 3), "copy_out": round(t[7] * 1e3, 3)}
     print(json.dumps(rec), flush=True)
     if scheme != "single":
         return
