@@ -254,6 +254,62 @@ def host_buffer_rates(eng, scheme: str, arrays: dict, expect, calls: int = 4):
     return out, ok
 
 
+MAX_SCLK_GHZ = 2.4          # MI355X_MICROARCH.md: peak engine clock; the ceiling when the clock cannot be sampled
+
+
+def microbench_ceiling():
+    """The best cycles per wave-instruction the chip issued on the mix of the Montgomery block (tools/microbench, stage
+    mont-mix, priced at the clock sampled beside it): an empirical ceiling, reported next to the bound."""
+    path = os.path.join(ROOT, "profiles", "microbench_r03.jsonl")
+    best = None
+    try:
+        for line in open(path):
+            if not line.startswith("{"):
+                continue
+            r = json.loads(line)
+            if str(r.get("op", "")).startswith("mont-mix") and r.get("cycles_per_wave_instr_per_simd_at_sclk"):
+                c = r["cycles_per_wave_instr_per_simd_at_sclk"]
+                if r.get("waves_per_simd", 0) >= 2 and (best is None or c < best[0]):
+                    best = (c, r["waves_per_simd"], r.get("sclk_mhz"))
+    except (OSError, ValueError):
+        return None
+    return best
+
+
+def alu_roofline(pmc: dict, kernel_ms: float, clocks) -> dict:
+    """The binding roofline: vector-integer issue.  A SIMD of 16 lanes needs 4 cycles for a wave of 64
+    lanes on the multiplier array (v_mul_lo_u32 measured at 4.00-4.08 cycles at the sampled clock, v_mad_u64_u32 at
+    4.57-4.97) and 2 cycles for the simple 32-bit operations (v_add_u32, v_and_b32: 2.39-2.59): with I wave-instructions
+    per launch of which I64 are of the four-cycle class (PMC: SQ_INSTS_VALU, SQ_INSTS_VALU_INT64, committed pass of THIS
+    code), no schedule can need fewer than 4 I64 + 2 (I - I64) SIMD-cycles.  Against the cycles the chip had -- 1 024 SIMDs x
+    the shader clock sampled beside the timed loop x the launch time -- that is `frac`, at most 1 by construction.
+    Without a clock sample the peak clock stands in (a higher ceiling, a lower fraction)."""
+    insts = pmc.get("valu_wave_instr_per_launch")
+    if not insts:
+        return None
+    i64 = pmc.get("valu_int64_wave_instr_per_launch")
+    share = (i64 / insts) if i64 else 1.0          # no class counts: price every instruction at four cycles (still a bound)
+    floor = 4.0 * share + 2.0 * (1.0 - share)
+    sclk = (clocks or {}).get("sclk_mhz_median")
+    ghz = sclk / 1e3 if sclk else MAX_SCLK_GHZ
+    rate = insts / (kernel_ms * 1e-3)
+    peak = 1024 * ghz * 1e9 / floor
+    cycles = 1024 * ghz * 1e9 / rate
+    out = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instr/s", "frac": rate / peak,
+           "sclk_ghz": ghz, "sclk_sampled": bool(sclk), "clock_samples": (clocks or {}).get("samples"),
+           "power_w_median": (clocks or {}).get("power_w_median"),
+           "cycles_per_wave_instr": cycles, "floor_cycles_per_wave_instr": floor, "int64_class_share": share if i64 else None,
+           "valu_wave_instr_per_launch": insts, "valu_wave_instr_per_64_verifies": insts / (pmc["items"] / 64),
+           "source": pmc.get("source"),
+           "note": "floor = 4 cycles x share of 64-bit multiply-add / shift instructions + 2 cycles x the rest; frac = floor / cycles"}
+    emp = microbench_ceiling()
+    if emp:
+        out["empirical"] = {"cycles_per_wave_instr": emp[0], "waves_per_simd": emp[1], "sclk_mhz": emp[2],
+                            "frac": emp[0] / cycles,
+                            "source": "profiles/microbench_r03.jsonl, stage mont-mix (70 % multiply-adds on independent accumulators)"}
+    return out
+
+
 def csrc_hash() -> str:
     """SHA-256 over the kernel sources: ties a committed PMC profile to the code it was taken from."""
     import hashlib
@@ -362,6 +418,18 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
+    # The shader clock under this load, for the ALU roofline: sampled beside an untimed repetition of the same K steps,
+    # not beside the timed ones -- the query itself (SMU round trip) costs the loop 3 % (profiles/r03_clock_sampling_ab.txt)
+    clocks = None
+    if rank == 0 and not args.no_clock_sampling:
+        from jubjub_schnorr_amd.tools.clocks import ClockSampler
+        with ClockSampler(torch.cuda.current_device()) as sampler:
+            for _ in range(args.steps):
+                run_verify()
+            torch.cuda.synchronize()
+        clocks = sampler.summary()
+        if clocks:
+            clocks["when"] = "an untimed repetition of the timed loop (same batches, same kernels)"
 
     # bit-exact check against the by-construction expectation (every rank)
     ok_status = bool(torch.equal(st, expect))
@@ -382,15 +450,7 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
         pmc = committed_pmc(scheme + ("_unique_keys" if n_keys >= n else ""), n)
     if pmc:
         traffic = pmc.get("hbm_bytes_per_launch")
-        # the binding roofline: VALU issue.  Instruction count per launch from the committed PMC pass
-        # of THIS code (hash-checked), rate from THIS run's kernel time; ceiling = 1024 SIMDs issuing one
-        # wave-instruction every 4.2 cycles (microbenchmarked cost of the cheapest multiply) at 2.4 GHz nominal
-        insts = pmc.get("valu_wave_instr_per_launch")
-        if insts:
-            rate = insts / (kernel_ms * 1e-3)
-            peak = 1024 * 2.4e9 / 4.2
-            alu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instr/s", "frac": rate / peak,
-                   "valu_wave_instr_per_64_verifies": insts / (n / 64), "source": pmc.get("source")}
+        alu = alu_roofline(pmc, kernel_ms, clocks)
     rec = {
         "value": n * world * args.steps / elapsed,
         "unit": "verifications/s",
@@ -409,6 +469,7 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
                      "note": "integer-ALU bound path (SURVEY.md 8d): HBM is not the limiter, see alu_roofline and DESIGN.md 6; "
                              "traffic / alu_roofline are null unless profiles/pmc_latest.json was measured on this csrc hash"},
         "alu_roofline": alu,
+        "clocks": clocks,
     }
     if world == 1 and not (args.wire or args.ext or args.no_two_streams) and scheme == "single" and n_keys == N_KEYS:
         # Secondary figure, never `value`: the same K batches issued on two streams in turn.  Two big calls in flight
@@ -451,6 +512,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the secondary two-stream figure (profiling passes: overlapping kernels would blur per-kernel times)")
+    ap.add_argument("--no-clock-sampling", action="store_true",
+                    help="do not sample the shader clock beside the timed loop (alu_roofline then prices the ceiling at the peak clock)")
     ap.add_argument("--no-host-buffers", action="store_true",
                     help="skip the secondary host-buffer figures (profiling passes)")
     ap.add_argument("--wire", action="store_true",
@@ -536,6 +599,7 @@ def main():
             "bit_exact": head["bit_exact"],
             "roofline": head["roofline"],
             "alu_roofline": head["alu_roofline"],
+            "clocks": head.get("clocks"),
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
@@ -547,7 +611,7 @@ def main():
             out["schemes"] = {s: records[s] for s in schemes[1:]}
         if unique is not None:
             out["unique_keys"] = {k: unique[k] for k in ("value", "unit", "ms_per_step", "workload", "distinct_keys_per_gpu",
-                                                          "bit_exact", "roofline")}
+                                                          "bit_exact", "roofline", "alu_roofline", "clocks")}
             out["unique_keys"]["note"] = ("single scheme, every signature under its own public key: the key-table path cannot "
                                           "engage; `value` above is the SURVEY.md 8(d) workload, whose 4 096 keys repeat")
         print(json.dumps(out), flush=True)

@@ -74,7 +74,7 @@ def main():
         c, m = read_counters(d)
         counters.update(c)
         meta = m or meta
-    summary = {"round": 2, "variant": variant, "csrc_sha256": bench.csrc_hash(),
+    summary = {"round": 3, "variant": variant, "csrc_sha256": bench.csrc_hash(),
                "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --scheme " + scheme + " --steps 3 --warmup 1 "
                           "--no-cpu-baseline (one pass per counter group); kernel times from a separate "
                           "rocprofv3 --kernel-trace --stats run",
@@ -108,6 +108,14 @@ def main():
         valu = per_batch["SQ_INSTS_VALU"]
         summary["valu_wave_instr_per_launch"] = valu
         summary["valu_wave_instr_per_64_verifies"] = valu / ((1 << 20) / 64)
+        if "SQ_INSTS_VALU_INT64" in per_batch:
+            # the counter takes v_mad_u64_u32, v_mad_i64_i32 and the 64-bit shifts / adds (calibrated on the single-opcode
+            # kernels of tools/microbench under the same counters: profiles/r03_pmc_counter_calibration.txt): the
+            # instructions that occupy a SIMD for four cycles a wave
+            summary["valu_int64_wave_instr_per_launch"] = per_batch["SQ_INSTS_VALU_INT64"]
+            summary["valu_int64_share"] = per_batch["SQ_INSTS_VALU_INT64"] / valu
+        if "SQ_INSTS_VALU_INT32" in per_batch:
+            summary["valu_int32_wave_instr_per_launch"] = per_batch["SQ_INSTS_VALU_INT32"]
         overlapped = stats.get("key_verify_kernel", {}).get("avg_ms", 0.0) > 0.05      # key-table path: kernels on two streams
         if "GRBM_GUI_ACTIVE" in per_batch and batch_ms and not overlapped:
             cycles = per_batch["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
@@ -132,6 +140,7 @@ def main():
         latest = {"csrc_sha256": summary["csrc_sha256"], "schemes": {}}
     latest["schemes"][scheme + ("_unique_keys" if unique else "")] = {"items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
                                  "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
+                                 "valu_int64_wave_instr_per_launch": summary.get("valu_int64_wave_instr_per_launch"),
                                  "source": f"profiles/{tag}_pmc_summary{suffix}.json"}
     json.dump(latest, open(latest_path, "w"), indent=1)
     print(json.dumps({k: summary[k] for k in summary if k not in ("counters",)}, indent=1))

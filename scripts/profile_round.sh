@@ -11,8 +11,9 @@ for S in $SCHEMES single_unique; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_${S}_trace -- $B --steps 5 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_trace.log 2>&1 &&
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${T}_${S}_fetch -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_fetch.log 2>&1 &&
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${T}_${S}_write -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_write.log 2>&1 &&
-  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/prof_${T}_${S}_sq -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_sq.log 2>&1 || exit 1
-  (cd $R && JJS_PMC_SCHEME=$SS JJS_PMC_UNIQUE_KEYS=$U python jubjub_schnorr_amd/tools/pmc_summary.py $T "$T" gpurun_out/prof_${T}_${S}_trace gpurun_out/prof_${T}_${S}_fetch gpurun_out/prof_${T}_${S}_write gpurun_out/prof_${T}_${S}_sq > gpurun_out/pmc_${T}_${S}.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/prof_${T}_${S}_sq -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_sq.log 2>&1 &&
+  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 --output-format csv -d $R/gpurun_out/prof_${T}_${S}_int -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_${S}_int.log 2>&1 || exit 1
+  (cd $R && JJS_PMC_SCHEME=$SS JJS_PMC_UNIQUE_KEYS=$U python jubjub_schnorr_amd/tools/pmc_summary.py $T "$T" gpurun_out/prof_${T}_${S}_trace gpurun_out/prof_${T}_${S}_fetch gpurun_out/prof_${T}_${S}_write gpurun_out/prof_${T}_${S}_sq gpurun_out/prof_${T}_${S}_int > gpurun_out/pmc_${T}_${S}.log 2>&1
    find gpurun_out/prof_${T}_${S}_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/${T}_kernel_stats_${S}.csv \; )
 done
 cd $R
