@@ -182,16 +182,21 @@ int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t*
 
 /* ---- multisignature: batch verify_share / combine (reference src/multisig.rs:284-387, 440-500) -------
  * Transcript t owns participants [offsets[t], offsets[t+1]) of the flattened device arrays z (N x 32),
- * PK, R, S (N x 64 affine); m is B x 32.  `offsets` is a HOST array of B + 1 entries starting at 0; every
- * transcript needs 1..256 participants (otherwise -1, the reference's InvalidMultisigTranscript).
+ * PK, R, S (N x 64 affine); m is B x 32.  `offsets` is a HOST array of B + 1 non-decreasing entries starting at 0.
+ * A transcript may have any number of participants (the reference takes any non-empty transcript); one without
+ * participants gets transcript_status 5, the reference's InvalidMultisigTranscript, and does not affect the others.
+ * (Transcripts of more than 256 participants take a slower route into the call: their two sponge tags are computed
+ * on the host and the call waits for their upload.  The hash chains of a transcript run inside one lane each, so the time
+ * grows with the square of the participant count: 1 000 participants take about a second.)
  * Outputs (device): share_status[i] = 0 when z_i*G + (c*d_i)*PK_i == R_i + a*S_i, 4 (InvalidMultisigShare)
  * when not, 3 for a non-canonical encoding (z_i, a coordinate, or the transcript's m); transcript_status[t]
  * (B bytes, nullable) = 0 when `combine` returns a signature, else the status of the transcript's first failing
- * share (the reference's `combine` stops there, src/multisig.rs:340-353); agg_pk[t] = aggregate_pk(pk_vec) (64 B
+ * share (the reference's `combine` stops there, src/multisig.rs:340-353), or 5; agg_pk[t] = aggregate_pk(pk_vec) (64 B
  * affine); and what `combine` returns: sig_u[t] = sum z_i (32 B), sig_R[t] = RSa (64 B affine) -- both all-zero
  * for a transcript whose status is not 0 (no signature comes out of bad shares).
  * Like the reference, the points are not validated.  Asynchronous on `stream`. */
 #define JJS_STATUS_INVALID_SHARE 4
+#define JJS_STATUS_INVALID_TRANSCRIPT 5
 int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const void* S, const void* m,
                              const uint32_t* offsets_host, size_t n_transcripts, void* share_status, void* transcript_status,
                              void* agg_pk, void* sig_u, void* sig_R, void* stream);

@@ -14,7 +14,7 @@
 
 namespace jjs {
 
-enum : uint32_t { ST_INVALID_SHARE = 4 };
+enum : uint32_t { ST_INVALID_SHARE = 4, ST_INVALID_TRANSCRIPT = 5 };
 constexpr int EXT_WORDS = 36;
 
 struct msig_params {
@@ -26,7 +26,10 @@ struct msig_params {
     uint8_t *agg_pk, *sig_u, *sig_R;     // B x 64, B x 32, B x 64 (what aggregate_pk / combine return)
     uint8_t* transcript_status;          // B bytes: 0 = combine returns the signature; else the first share's failure
     uint32_t *tr_of, *d_words, *dpk, *e_pt, *a_words, *c_words;   // scratch: N, N x 8, N x 36, N x 36, B x 8, B x 8
-    const uint32_t* tags;                // SAFE tags [JJS_LONG_TAGS][9]
+    const uint32_t* tags;                // SAFE tags [JJS_LONG_TAGS][9]: transcripts of up to JJS_MSIG_MAX_PARTICIPANTS participants
+    const uint32_t* long_tags;           // [B][2][9], or nullptr: the two tags of every longer transcript, computed by the host
+                                         // for this call (csrc/safe_tag.h); rows of the other transcripts are not read
+    uint32_t max_table_participants, pad2_;
     const uint32_t* comb_g;
     uint32_t* lane_ws;                   // WS_WORDS_PER_LANE per resident lane
 };
@@ -35,6 +38,11 @@ JJS_HD fe_n load_tag(const uint32_t* tags, int n_inputs) {
     fe_n t;
     for (int i = 0; i < 9; ++i) t.l[i] = tags[(size_t)n_inputs * 9 + i];
     return t;
+}
+// the tag of transcript t's hash number `which` (0: delinearisation, 2 + 2n inputs; 1: a, 3 + 4n inputs)
+JJS_HD fe_n msig_tag(const msig_params& P, uint32_t t, uint32_t participants, int which, int n_inputs) {
+    if (participants > P.max_table_participants) return load_tag(P.long_tags, (int)(2 * t) + which);
+    return load_tag(P.tags, n_inputs);
 }
 JJS_HD void store_ext(uint32_t* dst, const ext_pt& p) {
     for (int i = 0; i < 9; ++i) { dst[i] = p.x.l[i]; dst[9 + i] = p.y.l[i]; dst[18 + i] = p.z.l[i]; dst[27 + i] = p.t.l[i]; }
@@ -56,7 +64,7 @@ JJS_HD void msig_delin_item(const msig_params& P, uint64_t i, uint32_t* ws) {
     const uint32_t t = P.tr_of[i], lo = P.offsets[t], hi = P.offsets[t + 1];
     const int n_in = 2 + 2 * (int)(hi - lo);
     const fe_src pk{P.PK, 64, 0};
-    fe_n dg = poseidon_digest_tagged(n_in, load_tag(P.tags, n_in), [&](int e) {
+    fe_n dg = poseidon_digest_tagged(n_in, msig_tag(P, t, hi - lo, 0, n_in), [&](int e) {
         return e < 2 ? load_fq(pk, i, 32u * (uint32_t)e) : load_fq(pk, lo + (uint64_t)((e - 2) >> 1), 32u * (uint32_t)(e & 1));
     });
     const words8 d = truncate250(dg);
@@ -76,7 +84,7 @@ JJS_HD void msig_agg_item(const msig_params& P, uint32_t t) {
     store_point(P.agg_pk, t, agg);
     const int n_in = 3 + 4 * (int)(hi - lo);
     const fe_src aggs{P.agg_pk, 64, 0}, ms{P.m, 32, 0}, rs{P.R, 64, 0}, ss{P.S, 64, 0};
-    fe_n dg = poseidon_digest_tagged(n_in, load_tag(P.tags, n_in), [&](int e) {
+    fe_n dg = poseidon_digest_tagged(n_in, msig_tag(P, t, hi - lo, 1, n_in), [&](int e) {
         if (e < 2) return load_fq(aggs, t, 32u * (uint32_t)e);
         if (e == 2) return load_fq(ms, t);
         const int k = e - 3;                     // R_i.u, R_i.v, S_i.u, S_i.v per participant
@@ -141,9 +149,16 @@ JJS_HD void msig_share_item(const msig_params& P, uint64_t i, uint32_t* ws) {
 // pass 6 (lane per transcript): what `combine` returns (src/multisig.rs:326-360): the signature only when every
 // share of the transcript verified; otherwise the status of the first failing share, and no signature -- the
 // outputs are cleared so that a caller who ignores the statuses cannot pick up an aggregate built from bad shares.
+// A transcript without participants is the reference's InvalidMultisigTranscript (src/multisig.rs:332-338): status 5 for
+// that transcript alone, nothing out (its aggregate key is cleared as well).
 JJS_HD void msig_verdict_item(const msig_params& P, uint32_t t) {
     uint32_t st = ST_OK;
     for (uint32_t i = P.offsets[t + 1]; i-- > P.offsets[t];) st = P.share_status[i] ? P.share_status[i] : st;
+    if (P.offsets[t + 1] == P.offsets[t]) {
+        st = ST_INVALID_TRANSCRIPT;
+        store_words(P.agg_pk, 2 * (uint64_t)t, small_words(0));
+        store_words(P.agg_pk, 2 * (uint64_t)t + 1, small_words(0));
+    }
     if (P.transcript_status) P.transcript_status[t] = (uint8_t)st;
     if (st != ST_OK) {
         store_words(P.sig_u, t, small_words(0));

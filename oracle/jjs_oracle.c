@@ -576,6 +576,33 @@ int jjo_poseidon(const uint8_t *inputs, size_t k, size_t n, uint8_t *out, int th
     }
     return bad ? -1 : 0;
 }
+/* The same sponge for a transcript of any length (multisig: 2 + 2n and 3 + 4n inputs): the SAFE tag is supplied by the
+ * caller as 32 canonical bytes (oracle/jjs_oracle.py sponge_tag: BLAKE2b through hashlib).  out = untruncated digests. */
+int jjo_poseidon_tagged(const uint8_t *inputs, size_t k, size_t n, const uint8_t *tag, uint8_t *out, int threads) {
+    if (k < 1) return -1;
+    int nt = pick_threads(threads); (void)nt;
+    fe tg;
+    if (!fq_from_bytes(&tg, tag)) return -1;
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(| : bad)
+    for (long i = 0; i < (long)n; ++i) {
+        fe s[5], x;
+        memset(&x, 0, sizeof(x));
+        s[0] = tg;
+        for (int j = 1; j < 5; ++j) fq_zero(&s[j]);
+        int pos = 0, ok = 1;
+        for (size_t j = 0; j < k && ok; ++j) {
+            ok &= fq_from_bytes(&x, inputs + 32 * (k * (size_t)i + j));
+            if (pos == 4) { hades_permute(s); pos = 0; }
+            fq_add(&s[1 + pos], &s[1 + pos], &x);
+            ++pos;
+        }
+        if (!ok) { bad |= 1; continue; }
+        hades_permute(s);
+        fq_to_bytes(out + 32 * i, &s[1]);
+    }
+    return bad ? -1 : 0;
+}
 int jjo_scalar_mul(const uint8_t *P, const uint8_t *k, size_t n, uint8_t *out, int threads) {
     int nt = pick_threads(threads); (void)nt;
     int bad = 0;

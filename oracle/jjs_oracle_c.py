@@ -42,6 +42,7 @@ def load(native: bool = False):
         "jjo_sign_vargen": [P, P, P, P, Z, P, P, P, P, I],
         "jjo_fq_mul": [P, P, Z, P],
         "jjo_poseidon": [P, Z, Z, P, I],
+        "jjo_poseidon_tagged": [P, Z, Z, P, P, I],
         "jjo_scalar_mul": [P, P, Z, P, I],
         "jjo_point_flags": [P, Z, P, I],
         "jjo_point_add": [P, P, Z, P],
@@ -143,6 +144,18 @@ def poseidon(inputs, threads=0):
     assert w == 32
     out = np.empty((n, 32), np.uint8)
     assert load().jjo_poseidon(_p(inputs), k, n, _p(out), threads) == 0
+    return out
+
+
+def poseidon_any(inputs, threads=0):
+    """inputs (n, k, 32), any k >= 1 -> (n, 32) untruncated digests; the SAFE tag of k comes from the Python oracle."""
+    import jjs_oracle as o
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+    n, k, w = inputs.shape
+    assert w == 32
+    tag = np.frombuffer(o.sponge_tag(k).to_bytes(32, "little"), np.uint8).copy()
+    out = np.empty((n, 32), np.uint8)
+    assert load().jjo_poseidon_tagged(_p(inputs), k, n, _p(tag), _p(out), threads) == 0
     return out
 
 

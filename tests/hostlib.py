@@ -121,6 +121,13 @@ def multisig(z, PK, R, S, m, offsets):
     return status, agg, su, sr, ts
 
 
+def safe_tag(n_inputs: int, table: bool = False):
+    out = np.zeros(9, np.uint32)
+    fn = load().jjs_host_safe_tag_table if table else load().jjs_host_safe_tag
+    assert fn(ctypes.c_uint32(n_inputs), _p(out)) == 0
+    return out
+
+
 def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 

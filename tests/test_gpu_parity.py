@@ -449,6 +449,18 @@ def test_multisig_batch(eng, reference_kat):
     check_multisig(run, reference_kat)
 
 
+def test_multisig_long_and_empty_transcripts(eng):
+    """Transcripts of 257 and 1 000 participants (beyond the generated tag table: the tags are computed at call time,
+    reference src/multisig.rs:326-338 takes any non-empty transcript), an empty transcript (status 5, alone) and ordinary
+    ones in one call, everything `combine` returns against the oracle."""
+    from test_hostbuild import check_long_multisig
+
+    def run(z, PK, R, S, m, offs):
+        out = eng.multisig_combine(dev(z), dev(PK), dev(R), dev(S), dev(m), offs)
+        return tuple(host(t) for t in out)
+    check_long_multisig(run, sizes=(257, 1000))
+
+
 def test_multisig_many_transcripts(eng):
     """4096 copies of ragged oracle transcripts (different corruption pattern per copy is not needed:
     the point is many transcripts in flight and the per-transcript outputs staying separate)."""

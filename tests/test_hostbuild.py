@@ -196,6 +196,85 @@ def test_decompress_matches_oracle():
     assert n_fail >= 10
 
 
+def test_safe_tag_computed_at_call_time():
+    """csrc/safe_tag.h (BLAKE2b and the reduction, written for the host side of the multisig entry point) against the
+    oracle's tag (hashlib) for lengths inside and far outside the generated table, and against the table itself."""
+    R261 = pow(2, 261, o.Q)
+    for n in (1, 2, 5, 16, 17, 516, 1027, 1028, 2002, 4003, 100003, (1 << 24) * 4 + 3):
+        want = o.sponge_tag(n) * R261 % o.Q
+        limbs = [(want >> (29 * i)) & 0x1FFFFFFF for i in range(9)]
+        assert hl.safe_tag(n).tolist() == limbs, n
+        if n < 1028:
+            assert hl.safe_tag(n, table=True).tolist() == limbs, n
+
+
+def long_multisig_transcript(n: int, seed: int, corrupt=()):
+    """One valid transcript of n participants with everything `combine` returns, built with the secret keys so that it
+    costs a handful of scalar multiplications instead of 4 n: d_i from the C oracle's sponge (any length), then
+    pk_agg = (sum d_i sk_i) G, RSa = (sum r_i + a sum s_i) G, c, z_i = r_i + s_i a - c d_i sk_i (src/multisig.rs:213-257,
+    440-500).  Points as the C oracle computes them (sk G etc.).  Returns the arrays and (agg, u, RSa, statuses)."""
+    import jjs_oracle_c as oc
+    from helpers import pt_bytes, to_int, to_pt
+    rng = np.random.default_rng(seed)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (o.R_ORDER - 1) + 1  # noqa: E731
+    sks, rs, ss = [rnd() for _ in range(n)], [rnd() for _ in range(n)], [rnd() for _ in range(n)]
+    G = np.tile(pt_bytes(o.G), (n, 1))
+    PK, R, S = (oc.scalar_mul(G, fe_arr(v)) for v in (sks, rs, ss))
+    msg = int.from_bytes(rng.bytes(40), "little") % o.Q
+    pre = np.empty((n, 2 + 2 * n, 32), np.uint8)
+    pre[:, 0] = PK[:, :32]; pre[:, 1] = PK[:, 32:]
+    pre[:, 2::2] = PK[:, :32][None]; pre[:, 3::2] = PK[:, 32:][None]
+    ds = [to_int(r) & ((1 << 250) - 1) for r in oc.poseidon_any(pre)]
+    agg = o.mul(o.G, sum(d * k for d, k in zip(ds, sks)) % o.R_ORDER)
+    pre = np.empty((1, 3 + 4 * n, 32), np.uint8)
+    pre[0, 0], pre[0, 1], pre[0, 2] = fe_bytes(agg[0]), fe_bytes(agg[1]), fe_bytes(msg)
+    pre[0, 3::4] = R[:, :32]; pre[0, 4::4] = R[:, 32:]; pre[0, 5::4] = S[:, :32]; pre[0, 6::4] = S[:, 32:]
+    a = to_int(oc.poseidon_any(pre)[0]) & ((1 << 250) - 1)
+    rsa = o.mul(o.G, (sum(rs) + a * sum(ss)) % o.R_ORDER)
+    c = o.digest_truncated([rsa[0], rsa[1], agg[0], agg[1], msg])
+    zs = [(rs[i] + ss[i] * a - c * ds[i] * sks[i]) % o.R_ORDER for i in range(n)]
+    st = [0] * n
+    for j in corrupt:
+        zs[j] = (zs[j] + 1) % o.R_ORDER; st[j] = 4
+    return fe_arr(zs), PK, R, S, fe_arr([msg]), (agg, sum(zs) % o.R_ORDER, rsa, st)
+
+
+def check_long_multisig(run, sizes=(257, 300)):
+    """Transcripts of more than 256 participants (the generated tag table ends there; their tags are computed at call
+    time), an empty transcript (InvalidMultisigTranscript for it alone) and ordinary ones in ONE call."""
+    from helpers import make_multisig_batch, pt_bytes
+    parts, infos, offs = [], [], [0]
+    for k, n in enumerate(sizes):
+        z, PK, R, S, m, info = long_multisig_transcript(n, seed=40 + k, corrupt=(n - 1,) if k == 1 else ())
+        parts.append((z, PK, R, S, m)); infos.append(info); offs.append(offs[-1] + n)
+    infos.append(None); offs.append(offs[-1])                  # an empty transcript in the middle
+    parts.append((np.empty((0, 32), np.uint8), np.empty((0, 64), np.uint8), np.empty((0, 64), np.uint8), np.empty((0, 64), np.uint8),
+                  fe_arr([7])))
+    z2, PK2, R2, S2, m2, offs2, want2, info2 = make_multisig_batch(3, seed=77, max_n=4, corrupt=False)
+    for t in range(3):
+        sl = slice(int(offs2[t]), int(offs2[t + 1]))
+        parts.append((z2[sl], PK2[sl], R2[sl], S2[sl], m2[t:t + 1])); infos.append(info2[t] + ([0] * (sl.stop - sl.start),))
+        offs.append(offs[-1] + sl.stop - sl.start)
+    Z, P_, R_, S_, M = (np.concatenate([p[i] for p in parts]) for i in range(5))
+    st, agg, su, sr, ts = run(Z, P_, R_, S_, M, offs)
+    for t, info in enumerate(infos):
+        lo, hi = offs[t], offs[t + 1]
+        if info is None:
+            assert ts[t] == 5 and not agg[t].any() and not su[t].any() and not sr[t].any()
+            continue
+        a_pk, u, rsa, want = info
+        assert st[lo:hi].tolist() == list(want), t
+        bad = any(want)
+        assert ts[t] == (4 if bad else 0), t
+        assert agg[t].tobytes() == pt_bytes(a_pk).tobytes(), t
+        assert sr[t].tobytes() == (bytes(64) if bad else pt_bytes(rsa).tobytes()), t
+        assert su[t].tobytes() == (bytes(32) if bad else o.le32(u)), t
+
+
+def test_multisig_long_and_empty_transcripts():
+    check_long_multisig(hl.multisig, sizes=(257,))
+
+
 def check_multisig(run, reference_kat):
     from helpers import make_multisig_batch, pt_bytes
     # 1. the reference's KAT transcript (src/multisig.rs:544-672): shares valid, combined signature bytes
