@@ -89,6 +89,9 @@ int jjs_init(int device_count);
 void jjs_shutdown(void);
 /* Number of devices the process drives (0 before jjs_init). */
 int jjs_device_count(void);
+/* Ranks of the in-library RCCL clique that sums the tallies of the host-buffer calls: the number of devices when
+ * jjs_init set up more than one (real) device, else 0 (one device: nothing to sum). */
+int jjs_collective_ranks(void);
 const char* jjs_last_error(void);
 /* ABI version: bumped on any signature change. */
 int jjs_abi_version(void);

@@ -23,6 +23,7 @@ SIGNATURES = {
     "jjs_last_error": [],
     "jjs_abi_version": [],
     "jjs_device_count": [],
+    "jjs_collective_ranks": [],
     "jjs_verify_single": [_P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_double": [_P, _P, _P, _P, _P, _P, _Z, _P, _P],
     "jjs_verify_vargen": [_P, _P, _P, _P, _P, _Z, _P, _P],

@@ -2015,6 +2015,11 @@ int jjs_device_count(void) {
     return (int)L.devs.size();
 }
 
+int jjs_collective_ranks(void) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    return L.comms_up ? (int)L.devs.size() : 0;
+}
+
 int jjs_stream_sync(void* stream) {
     {
         std::lock_guard<std::mutex> lock(L.mu);

@@ -18,11 +18,18 @@ def main(devices: int) -> None:
     import torch
     import jubjub_schnorr_amd as jjs
     from jubjub_schnorr_amd import _ffi
-    if torch.cuda.device_count() < devices:
+    real = torch.cuda.device_count() >= devices
+    if not real:
         _ffi.select_library(_ffi.PROFILING_LIB_PATH)
         assert _ffi.lib().jjs_debug_allow_virtual_devices(1) == 0
     eng = jjs.Engine(devices)
     assert eng.device_count == devices, eng.device_count
+    # which tally reduction this run exercises: with enough visible devices it must be the real one (start_comms():
+    # ncclCommInitAll over the driven devices, one ncclAllReduce per host-buffer call); logical devices sharing a card
+    # cannot form a clique and are summed on the host
+    ranks = _ffi.lib().jjs_collective_ranks()
+    print("TALLY REDUCTION:", f"RCCL clique of {ranks} ranks" if ranks else "host sum over logical devices (no clique)")
+    assert ranks == (devices if real else 0), (ranks, devices, torch.cuda.device_count())
     for scheme in ("single", "double", "vargen"):
         widths = [b.shape[1] for b in (make_batch(scheme, 1)[k] for k in ARG_ORDER[scheme])]
         # n = 0, fewer items than devices (empty blocks), ragged and larger blocks
