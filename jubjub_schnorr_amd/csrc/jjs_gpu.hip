@@ -1085,7 +1085,9 @@ bool small_path_applies(const verify_params& P) {
 //   (the equations; register-bound) and the resolve pass over the items verify queued (normally the invalid ones only);
 //   key-table path: the key kernels on the slot's key stream beside the hashes, then key_verify_kernel; whichever of
 //   verify_kernel / key_verify_kernel is not wanted leaves at once;  small batches take the latency path instead.
-enum : uint32_t { COLS_KEYS = 1, COLS_REST = 2, COLS_ALL = 3 };      // which columns of a range have just arrived
+// which columns of a range have just arrived: the key columns, the other columns the hashes read, or both; COLS_LATE (host-
+// buffer calls only) = the columns nothing reads before job_finish (u: the head launch of prepare_kernel does not touch it)
+enum : uint32_t { COLS_KEYS = 1, COLS_REST = 2, COLS_ALL = 3, COLS_LATE = 4 };
 struct staged_call {
     verify_params P{};
     bool wire = false;                // compressed points: W
@@ -1539,7 +1541,7 @@ struct device_restore {   // puts the calling thread back on the device it came 
 // staging and events are per device and only grow.  The tallies are summed over the devices with one RCCL all-reduce.
 // A failing block drains its streams before it reports, so nothing is in flight into the caller's or the library's
 // buffers when the call returns an error.
-struct host_col { const uint8_t* p; size_t width; bool key; };
+struct host_col { const uint8_t* p; size_t width; uint32_t group; };      // group: COLS_KEYS, COLS_REST or COLS_LATE
 // build-time knobs of the A/B runs recorded in DESIGN.md 6 (scripts/host_ab.sh)
 #ifndef JJS_HOST_LEAD_LOG2
 #define JJS_HOST_LEAD_LOG2 16            // items of the first piece (all columns) ...
@@ -1597,14 +1599,26 @@ int ensure_pinned(size_t bytes) {
     return JJS_OK;
 }
 
+// nothing may leave an extern "C" entry point by exception: the host-buffer calls allocate (block and piece lists)
+template <typename F>
+int no_throw(F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        return fail(JJS_ERR_HIP, "host-side failure: %s", e.what());
+    } catch (...) {
+        return fail(JJS_ERR_HIP, "host-side failure");
+    }
+}
 struct host_piece {
     size_t first, count;
-    uint32_t cols;             // COLS_KEYS, COLS_REST or COLS_ALL
+    uint32_t cols;             // the column groups it carries (COLS_*)
 };
 struct host_block {
     size_t lo = 0, hi = 0;
-    std::vector<host_piece> pieces;
-    size_t largest_bytes = 0;  // of a piece in the pinned staging slots
+    std::vector<host_piece> pieces;       // the plan in use
+    std::vector<host_piece> plans[2];     // [0] the late columns travel with the others, [1] they travel last (split calls)
+    size_t largest_bytes = 0;  // of a piece in the pinned staging slots, over both plans
     unsigned staging_threads = 1;
     int rc = JJS_OK;
     char err[512] = "";
@@ -1621,14 +1635,18 @@ struct host_block {
 //     within half the block, then the key columns of the rest, then its remaining columns in ranges of 2^17, 2^18, 2^18 ...
 //     items (ranges of equal size keep the staging copy of the next range shorter than the upload of this one);
 //   * a wire call hashes nothing before its keys are decoded (keys_gate_hashes): its key column goes first, whole.
-void plan_pieces(host_block& b, size_t nl, size_t row_keys, size_t row_rest, bool keys_gate_hashes) {
-    b.pieces.clear();
-    b.largest_bytes = 256;
+//   * the columns nothing reads before the equations (u) travel last, behind everything the hashes need, when the call
+//     hashes with the head launch (`late`: 16 % fewer bytes ahead of the first hashes of a single batch); else with the others.
+// row_keys / row_rest / row_late: bytes per item of the column groups.
+void plan_pieces(std::vector<host_piece>& pieces, size_t& largest_bytes, size_t nl, size_t row_keys, size_t row_rest, size_t row_late,
+                 bool keys_gate_hashes, bool late) {
+    pieces.clear();
+    const uint32_t rest = COLS_REST | (late ? 0u : COLS_LATE);       // the groups that travel as "the other columns"
     auto add = [&](size_t first, size_t count, uint32_t cols) {
         if (!count) return;
-        b.pieces.push_back(host_piece{first, count, cols});
-        const size_t bytes = count * ((cols & COLS_KEYS ? row_keys : 0) + (cols & COLS_REST ? row_rest : 0));
-        if (bytes > b.largest_bytes) b.largest_bytes = bytes;
+        pieces.push_back(host_piece{first, count, cols});
+        const size_t bytes = count * ((cols & COLS_KEYS ? row_keys : 0) + (cols & COLS_REST ? row_rest : 0) + (cols & COLS_LATE ? row_late : 0));
+        if (bytes > largest_bytes) largest_bytes = bytes;
     };
     // ranges: `first_len`, then times `growth` up to `cap`; a remainder of less than half a first range joins the range before it
     auto ranges = [&](size_t from, size_t first_len, size_t growth, size_t cap, uint32_t cols) {
@@ -1643,24 +1661,25 @@ void plan_pieces(host_block& b, size_t nl, size_t row_keys, size_t row_rest, boo
     };
     // very large blocks: larger pieces, so that their number stays within the events a device has
     size_t cap_keys = HOST_KEYS_ITEMS_MAX, cap_rest = HOST_REST_ITEMS_MAX;
-    if (nl > cap_keys * 10) cap_keys = ((nl + 9) / 10 + 255) & ~size_t(255);
-    if (nl > cap_rest * 20) cap_rest = ((nl + 19) / 20 + 255) & ~size_t(255);
+    if (nl > cap_keys * 8) cap_keys = ((nl + 7) / 8 + 255) & ~size_t(255);
+    if (nl > cap_rest * 16) cap_rest = ((nl + 15) / 16 + 255) & ~size_t(255);
     const bool keys_first = row_keys != 0 && nl >= KT_MIN_ITEMS && nl > 2 * HOST_LEAD_ITEMS;
     if (!keys_first) {
-        ranges(0, HOST_LEAD_ITEMS, 4, cap_rest, COLS_ALL);
-        return;
+        ranges(0, HOST_LEAD_ITEMS, 4, cap_rest, COLS_KEYS | rest);
+    } else {
+        size_t lead = 0;
+        if (!keys_gate_hashes) {
+            size_t next = HOST_LEAD_ITEMS;
+            do {
+                add(lead, next, COLS_KEYS | rest);
+                lead += next;
+                next = next * 2 < cap_rest ? next * 2 : cap_rest;
+            } while (lead + next <= nl / HOST_LEAD_SHARE_DEN * HOST_LEAD_SHARE_NUM);
+        }
+        ranges(lead, cap_keys, 1, cap_keys, COLS_KEYS);
+        ranges(lead, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, rest);
     }
-    size_t lead = 0;
-    if (!keys_gate_hashes) {
-        size_t next = HOST_LEAD_ITEMS;
-        do {
-            add(lead, next, COLS_ALL);
-            lead += next;
-            next = next * 2 < cap_rest ? next * 2 : cap_rest;
-        } while (lead + next <= nl / HOST_LEAD_SHARE_DEN * HOST_LEAD_SHARE_NUM);
-    }
-    ranges(lead, cap_keys, 1, cap_keys, COLS_KEYS);
-    ranges(lead, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, COLS_REST);
+    if (late && row_late) ranges(0, cap_keys, 1, cap_keys, COLS_LATE);
 }
 
 struct stage_task {          // one piece's pageable -> pinned copy, cut into T slices of every column
@@ -1702,7 +1721,7 @@ void stage_slice(void* ctx, unsigned t) {
     const size_t i0 = S.count * t / S.T, i1 = S.count * (t + 1) / S.T;
     uint8_t* q = S.dst;
     for (size_t k = 0; k < S.n_cols; ++k) {
-        if (!((S.cols[k].key ? COLS_KEYS : COLS_REST) & S.group)) continue;
+        if (!(S.cols[k].group & S.group)) continue;
         const size_t w = S.cols[k].width;
         stream_copy(q + i0 * w, S.cols[k].p + (S.lo + S.first + i0) * w, (i1 - i0) * w);
         q += S.count * w;
@@ -1746,6 +1765,17 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     uint8_t* const pst = g->pinned + HOST_SLOTS * slot_bytes;
     unsigned long long* const ptally = reinterpret_cast<unsigned long long*>(pst + pad256(nl));
     if (!g->stagers && b.staging_threads > 1) g->stagers = new (std::nothrow) staging_pool(b.staging_threads - 1);
+    // The call of this block (the builder picks its slot), and with it the upload order: the columns nothing reads before
+    // the equations (u) travel last when the call will hash with the head launch of prepare_kernel, which does not touch
+    // them -- i.e. when it tries the key tables (and is not a wire call, whose u sits inside the signature column).
+    if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
+    bool late = false;
+    for (size_t k = 0; k < n_cols; ++k) late = late || cols[k].group == COLS_LATE;
+    late = late && !J.C.wire && !small_path_applies(J.C.P) && key_path_applies(J.C.P) && ensure_key_pool() == JJS_OK;
+#if defined(JJS_HOST_NO_LATE)            // build-time knob of the A/B run recorded in DESIGN.md 6
+    late = false;
+#endif
+    b.pieces = b.plans[late ? 1 : 0];
     // The staging copy of piece i + 1 runs on the helper threads while this thread queues the uploads and the kernels of
     // piece i (some 0.1 ms of HIP calls per piece, during which the bus would otherwise wait for the next piece).
     stage_task tasks[HOST_SLOTS];
@@ -1760,7 +1790,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         if (i >= HOST_SLOTS) HIP_TRY(hipEventSynchronize(g->chunk_up[i - HOST_SLOTS]));      // the slot's previous upload has left it
         size_t piece_bytes = 0;
         for (size_t k = 0; k < n_cols; ++k)
-            if ((cols[k].key ? COLS_KEYS : COLS_REST) & pc.cols) piece_bytes += pc.count * cols[k].width;
+            if (cols[k].group & pc.cols) piece_bytes += pc.count * cols[k].width;
         stage_task& S = tasks[i % HOST_SLOTS];
         S = stage_task{cols, n_cols, b.lo, pc.first, pc.count, pc.cols, g->pinned + (i % HOST_SLOTS) * slot_bytes, 1};
         const unsigned threads = g->stagers ? g->stagers->helpers() + 1 : 1u;
@@ -1782,7 +1812,6 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     // the arena and the counters may still be in use by the previous call's last launches
     HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
     HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
-    if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
     if (int rc = job_begin(J, g->stream)) return rc;
     // The ranges of the block are queued on several streams in turn: a launch waits for every block of its predecessor on
     // the same stream, and a block of hashes lives for 1.4 ms, so on one stream (or two: scripts/host_timeline.sh) the chip
@@ -1800,7 +1829,17 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     for (size_t i = 0; i < np; ++i)
         if (b.pieces[i].cols & COLS_KEYS) last_key_piece = i;
     struct deferred { size_t first, count; hipStream_t cs; };
-    std::vector<deferred> waiting;                      // ranges whose hashes need the key kernels queued first (wire calls)
+    // ranges whose hashes cannot be queued yet: a wire call hashes behind its key kernels; and a call that was expected to
+    // hash with the head launch but does not after all (job_begin could not set the key tables up) reads u, which then
+    // travels last
+    std::vector<deferred> waiting;
+    const bool needs_late = late && !J.split;
+    size_t last_late_piece = np;
+    for (size_t i = 0; i < np; ++i)
+        if (b.pieces[i].cols & COLS_LATE) last_late_piece = i;
+    auto hashes_blocked = [&](size_t i) {
+        return (job_hash_needs_keys(J) && !J.keys_queued) || (needs_late && i < last_late_piece);
+    };
     for (size_t i = 0; i < np; ++i) {
         const host_piece& pc = b.pieces[i];
         uint8_t* const hp = g->pinned + (i % HOST_SLOTS) * slot_bytes;
@@ -1820,7 +1859,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         {
             uint8_t* q = hp;
             for (size_t k = 0; k < n_cols; ++k) {
-                if (!((cols[k].key ? COLS_KEYS : COLS_REST) & pc.cols)) continue;
+                if (!(cols[k].group & pc.cols)) continue;
                 const size_t w = cols[k].width;
                 HIP_TRY(hipMemcpyAsync(col_dev[k] + pc.first * w, q, pc.count * w, hipMemcpyHostToDevice, g->copy_stream));
                 q += pc.count * w;
@@ -1839,7 +1878,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         converted_on[i] = is;
         HIP_TRY(hipStreamWaitEvent(is, g->chunk_up[i], 0));
         if (is != cs && i < 2) HIP_TRY(hipStreamWaitEvent(is, g->host_begin, 0));     // behind job_begin's cleared flags
-        if (int rc = job_ingest(J, pc.first, pc.count, pc.cols, is)) return rc;
+        if (int rc = job_ingest(J, pc.first, pc.count, pc.cols & COLS_ALL, is)) return rc;
         HIP_TRY(hipEventRecord(g->chunk_done[i], is));
         if (is != cs) HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[i], 0));
         if (i == last_key_piece && J.try_keys) {
@@ -1847,8 +1886,12 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
             for (size_t j = 0; j <= i; ++j)
                 if (b.pieces[j].cols & COLS_KEYS) HIP_TRY(hipStreamWaitEvent(sl->key_stream, g->chunk_done[j], 0));
             if (int rc = job_keys(J)) return rc;
-            for (const deferred& d : waiting)
+        }
+        if (!waiting.empty() && !hashes_blocked(i)) {
+            for (const deferred& d : waiting) {
+                if (needs_late) HIP_TRY(hipStreamWaitEvent(d.cs, g->chunk_up[last_late_piece], 0));
                 if (int rc = job_hash(J, d.first, d.count, d.cs)) return rc;
+            }
             waiting.clear();
         }
         if (pc.cols & COLS_REST) {
@@ -1858,11 +1901,12 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
                 if ((o.cols & COLS_KEYS) && converted_on[j] != cs && o.first < pc.first + pc.count && pc.first < o.first + o.count)
                     HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[j], 0));
             }
-            if (job_hash_needs_keys(J) && !J.keys_queued) waiting.push_back(deferred{pc.first, pc.count, cs});
+            if (hashes_blocked(i)) waiting.push_back(deferred{pc.first, pc.count, cs});
             else if (int rc = job_hash(J, pc.first, pc.count, cs)) return rc;
         }
     }
     if (!waiting.empty()) return fail(JJS_ERR_ARG, "internal: ranges left waiting for the key kernels");
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->chunk_up[np - 1], 0));      // the equations read every column
     if (int rc = job_finish(J)) return rc;
 #if defined(JJS_PROFILING)
     const double t_queued = now();
@@ -1903,19 +1947,22 @@ int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uin
         if (staging_threads > HOST_STAGING_THREADS_MAX) staging_threads = HOST_STAGING_THREADS_MAX;
         if (staging_threads < 1) staging_threads = 1;
     }
-    size_t row_keys = 0, row_rest = 0;
-    for (size_t k = 0; k < n_cols; ++k) (cols[k].key ? row_keys : row_rest) += cols[k].width;
+    size_t row_keys = 0, row_rest = 0, row_late = 0;
+    for (size_t k = 0; k < n_cols; ++k)
+        (cols[k].group == COLS_KEYS ? row_keys : cols[k].group == COLS_LATE ? row_late : row_rest) += cols[k].width;
     for (size_t d = 0; d < nd; ++d) {
         host_block& b = blocks[d];
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
-        plan_pieces(b, b.hi - b.lo, row_keys, row_rest, keys_gate_hashes);
+        b.largest_bytes = 256;
+        plan_pieces(b.plans[0], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, keys_gate_hashes, false);
+        plan_pieces(b.plans[1], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, keys_gate_hashes, true);
         b.staging_threads = staging_threads;
     }
     auto work = [&](size_t d) {
         host_block& b = blocks[d];
         verify_job J;
-        b.rc = run_host_block(targets[d], cols, n_cols, b, status, build, J);
+        b.rc = no_throw([&] { return run_host_block(targets[d], cols, n_cols, b, status, build, J); });
         if (b.rc != JJS_OK) {
             // leave nothing in flight into the caller's arrays, the pinned slots or the counters
             snprintf(b.err, sizeof(b.err), "%s", t_err);
@@ -2209,7 +2256,7 @@ static int host_call(call_builder build, const host_col* cols, size_t n_cols, si
                      bool keys_gate_hashes = false) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    return run_host(cols, n_cols, n, status, tally, build, keys_gate_hashes);
+    return no_throw([&] { return run_host(cols, n_cols, n, status, tally, build, keys_gate_hashes); });
 }
 
 // ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
@@ -2230,17 +2277,17 @@ int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const vo
 }
 int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                       uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {PK, 64, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_affine_single, cols, 4, n, status, tally);
 }
 int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
                       const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {Rp, 64, false}, {PK, 64, true}, {PKp, 64, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {Rp, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {PKp, 64, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_affine_double, cols, 6, n, status, tally);
 }
 int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
                       size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 64, false}, {PK, 64, true}, {Gen, 64, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {Gen, 64, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_affine_vargen, cols, 5, n, status, tally);
 }
 
@@ -2258,15 +2305,15 @@ int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, s
     return resident_call(build_wire_vargen, d, n, status, tally, stream);
 }
 int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 64, false}, {pk, 32, true}, {m, 32, false}};
+    const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 32, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_wire_single, cols, 3, n, status, tally, true);
 }
 int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 96, false}, {pk, 64, true}, {m, 32, false}};
+    const host_col cols[] = {{sig, 96, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_wire_double, cols, 3, n, status, tally, true);
 }
 int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 64, false}, {pk, 64, true}, {m, 32, false}};
+    const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_wire_vargen, cols, 3, n, status, tally, true);
 }
 
@@ -2288,17 +2335,17 @@ int jjs_verify_vargen_ext_dev(const void* u, const void* R, const void* PK, cons
 }
 int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n, uint8_t* status,
                           uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {PK, 96, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_ext_single, cols, 4, n, status, tally);
 }
 int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
                           const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {Rp, 96, false}, {PK, 96, true}, {PKp, 96, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {Rp, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {PKp, 96, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_ext_double, cols, 6, n, status, tally);
 }
 int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m, size_t n,
                           uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, false}, {R, 96, false}, {PK, 96, true}, {Gen, 96, true}, {m, 32, false}};
+    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {Gen, 96, COLS_KEYS}, {m, 32, COLS_REST}};
     return host_call(build_ext_vargen, cols, 5, n, status, tally);
 }
 

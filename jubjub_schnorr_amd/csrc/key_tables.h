@@ -291,7 +291,8 @@ JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint
         const fe_n ru = load_fq(E.r, item), rv = load_fq(E.r, item, 32);
         eq_ok = ext_eq_affine(acc, ru, rv) && eq_ok;
     }
-    if (r.malformed || keys_malformed) return ST_MALFORMED;
+    // u < r is checked here: the head launch of prepare_kernel, which made r, does not read u (verify_core.h prep_phase)
+    if (r.malformed || keys_malformed || !words_lt(u, JJS_FR_WORDS)) return ST_MALFORMED;
     if (!r.valid || !keys_valid) return ST_INVALID_POINT;
     if (JJS_SKIP(P, 1u)) return eq_ok ? ST_OK : ST_INVALID_SIGNATURE;        // profiling only: no resolve pass
     // the equations hold: every R is a sum of torsion-free points; they fail: R's own subgroup test decides

@@ -745,10 +745,13 @@ JJS_HD bool keyed_mode(const verify_params& P) { return P.key_flag != nullptr &&
 
 // The device runs a batch that may take the key-table path in two launches, because whether it does is decided while
 // the first one runs (the keys are being counted beside it):
-//   PREP_HEAD  everything that does not depend on the decision: encodings, the cheap checks of the points that are not
-//              keys, the challenge;
-//   PREP_TAIL  what only the throughput path needs (the launch leaves at once when the key tables engaged): validity
-//              of the key points, half-size scalars, combined subgroup tests;
+//   PREP_HEAD  everything that does not depend on the decision: encodings of the transcript, the cheap checks of the points
+//              that are not keys, the challenge.  It does not read u at all (the challenge does not depend on it), so that
+//              a host-buffer call can send the u column last, behind everything the hashes need (jjs_gpu.hip
+//              run_host_block); the range check of u is made by whoever reads it next:
+//   PREP_TAIL  what only the throughput path needs (the launch leaves at once when the key tables engaged): u < r,
+//              validity of the key points, half-size scalars, combined subgroup tests; on the key-table path
+//              kt_finish_item checks u < r itself;
 //   PREP_ALL   both at once, with the decision already known (keyed_mode): every other caller.
 enum prep_phase : int { PREP_ALL = 0, PREP_HEAD = 1, PREP_TAIL = 2 };
 
@@ -787,9 +790,10 @@ JJS_HD void scalars_and_combined_tests(const verify_params& P, uint64_t item, bo
 JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool write_c = true, int coop = -1, prep_phase phase = PREP_ALL) {
     prep_record r;
     const bool keyed = phase == PREP_ALL && keyed_mode(P);
-    // 1. encodings: every transcript element (all point coordinates and m) < q, u < r
-    const words8 u = load_words(P.u, item);
-    bool malformed = !words_lt(u, JJS_FR_WORDS);
+    // 1. encodings: every transcript element (all point coordinates and m) < q, u < r (not in the head launch: see prep_phase)
+    const bool reads_u = phase != PREP_HEAD || JJS_SKIP(P, 2u);
+    const words8 u = reads_u ? load_words(P.u, item) : words8{};
+    bool malformed = phase != PREP_HEAD && !words_lt(u, JJS_FR_WORDS);
     if (P.pre_malformed) malformed = malformed || P.pre_malformed[item] != 0;
     for (uint32_t e = 0; e < P.n_hash; ++e) malformed = malformed || !words_lt(load_words(P.hash_in[e], item), JJS_Q_WORDS);
     r.malformed = malformed;
@@ -818,6 +822,7 @@ JJS_HD prep_record prepare_item(const verify_params& P, uint64_t item, bool writ
 // PREP_TAIL: completes the record of PREP_HEAD for a batch that turned the key tables down
 JJS_HD prep_record prepare_tail(const verify_params& P, uint64_t item, prep_record r) {
     const bool check_points = !JJS_SKIP(P, 1u) && !P.small_mode;
+    r.malformed = r.malformed || !words_lt(load_words(P.u, item), JJS_FR_WORDS);
     if (check_points) r.valid = points_valid(P, item, P.key_points_mask & ((1u << P.n_points) - 1u)) && r.valid;
     scalars_and_combined_tests(P, item, check_points, r);
     return r;

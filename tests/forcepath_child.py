@@ -36,9 +36,11 @@ def main() -> None:
                 st_h, tally_h = eng.verify(scheme, *[b[k] for k in ARG_ORDER[scheme]])           # host buffers
                 assert st_h.tolist() == want.tolist() and tally_h.tolist() == tally.cpu().numpy().tolist()
     # key-table path: both window widths on the same batch (218 signatures per key: the product takes the wide windows)
+    kt_cases = {}
     for scheme in ("single", "double", "vargen"):
         b = make_batch(scheme, 65536 + 37, seed=808, n_keys=300)
         want = oracle_verify(scheme, b)
+        kt_cases[scheme] = (b, want)
         for path in (0, 0x500):
             assert lib.jjs_debug_force_path(path) == 0
             st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
@@ -48,8 +50,7 @@ def main() -> None:
     # a device that cannot hold the key-table pool: the same batches take the throughput path, statuses unchanged, and the
     # path statistics say so (resident and host-buffer entry points)
     for scheme in ("single", "double", "vargen"):
-        b = make_batch(scheme, 65536 + 37, seed=808, n_keys=300)
-        want = oracle_verify(scheme, b)
+        b, want = kt_cases[scheme]
         before = eng.path_stats()
         assert lib.jjs_debug_fail_key_arena(1) == 0
         st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
@@ -63,7 +64,7 @@ def main() -> None:
     # keys crafted to collide in the dedup table: harmless under the per-call seed of the product; with the seed pinned
     # (what the sender would need to know) the probe limit sends the batch down the throughput path, statuses unchanged
     from helpers import crafted_collision_batch
-    b = crafted_collision_batch()
+    b = crafted_collision_batch(n_good=1 << 16)
     want = oracle_verify("single", b)
     for pinned in (0, 1):
         before = eng.path_stats()

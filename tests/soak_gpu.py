@@ -1,6 +1,7 @@
 """Soak: a BASELINE-size batch per scheme -- the bench mix plus small-order components injected into R / R' / Gen --
 with EVERY status compared with the C oracle (the reference's algorithm on all host cores), then the same batch
-compressed on the device and pushed through the wire entry points.  Collected under `-m gpu` by
+compressed on the device and pushed through the wire entry points, and then through the blocking host-buffer entry
+points in all three formats (affine, extended U || V || Z, wire: the piece-by-piece upload pipeline of run_host_block).  Collected under `-m gpu` by
 tests/test_soak_gpu.py; also runnable by hand on the GPU box:  python tests/soak_gpu.py [log2n] [out.json]"""
 import json
 import os
@@ -74,12 +75,26 @@ def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
         st_w, tally_w = eng.verify_wire(scheme, sig.contiguous(), pk.contiguous(), dev["m"])
         bad_w = int((st_w.cpu().numpy() != want).sum())
         print(f"{scheme}: wire entry point, mismatches {bad_w}", flush=True)
+        # the blocking host-buffer entry points on the same statuses: pageable arrays in, statuses out
+        from helpers import ext_on_device
+        names = ARG_ORDER[scheme]
+        st_h, tally_h = eng.verify(scheme, *[host[k] for k in names])
+        ext = [ext_on_device(eng, host[k], seed=5) if host[k].shape[1] == 64 else host[k] for k in names]
+        st_e, tally_e = eng.verify_ext(scheme, *ext)
+        st_hw, tally_hw = eng.verify_wire(scheme, sig.contiguous().cpu().numpy(), pk.contiguous().cpu().numpy(), host["m"])
+        bad_host = {"affine": int((st_h != want).sum()), "ext": int((st_e != want).sum()), "wire": int((st_hw != want).sum())}
+        tallies_host = [t.tolist() for t in (tally_h, tally_e, tally_hw)]
+        print(f"{scheme}: host-buffer entry points, mismatches {bad_host}", flush=True)
+        del ext
         report["schemes"][scheme] = {"oracle_status_histogram": hist, "gpu_tally": tally.cpu().numpy().tolist(),
                                      "gpu_tally_wire": tally_w.cpu().numpy().tolist(), "mismatches_affine": bad,
-                                     "mismatches_wire": bad_w, "oracle_seconds": round(t_cpu, 1)}
+                                     "mismatches_wire": bad_w, "mismatches_host_buffers": bad_host,
+                                     "host_buffer_tallies_equal": all(t == hist for t in tallies_host),
+                                     "oracle_seconds": round(t_cpu, 1)}
         del dev, comp, arrays
         torch.cuda.empty_cache()
-    report["ok"] = all(r["mismatches_affine"] == 0 and r["mismatches_wire"] == 0 and
+    report["ok"] = all(r["mismatches_affine"] == 0 and r["mismatches_wire"] == 0 and not any(r["mismatches_host_buffers"].values()) and
+                       r["host_buffer_tallies_equal"] and
                        r["gpu_tally"] == r["oracle_status_histogram"] == r["gpu_tally_wire"] for r in report["schemes"].values())
     return report
 

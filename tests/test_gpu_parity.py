@@ -688,7 +688,7 @@ def test_keys_crafted_to_collide_in_the_hash_table(eng):
     every status is the oracle's.  tests/forcepath_child.py runs the same batch with the seed pinned (profiling build):
     the probe sequences are then cut at KT_MAX_PROBES and the batch takes the throughput path."""
     from helpers import crafted_collision_batch
-    b = crafted_collision_batch()
+    b = crafted_collision_batch(n_good=1 << 16)
     want = oracle_verify("single", b)
     import time
     import torch
