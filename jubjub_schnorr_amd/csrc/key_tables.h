@@ -52,7 +52,7 @@ constexpr uint32_t KT_MAX_PROBES = 128;          // hash-table probes per key be
 constexpr uint32_t KT_KEY_MALFORMED = 1, KT_KEY_VALID = 2;
 constexpr int KT_BASE_WORDS = 36;
 // The bases and tables of the keys live in a pool that is sized by the number of distinct keys the slot's calls have
-// carried, not by the batch size (jjs_gpu.hip setup_keys): a pool column holds `narrow` keys with narrow windows or `wide`
+// carried, not by the batch size (verify_job.h setup_keys): a pool column holds `narrow` keys with narrow windows or `wide`
 // keys with wide ones, and these are the words its two regions need for that.
 JJS_HD constexpr size_t kt_max(size_t a, size_t b) { return a > b ? a : b; }
 JJS_HD constexpr size_t kt_base_words_for_keys(size_t narrow, size_t wide) {
@@ -96,7 +96,7 @@ struct key_params {
     // order[i], so the lanes of a wave look up the tables of one or two keys instead of 64
     uint32_t* order;         // [n]
     uint32_t* key_cursor;    // items per key, then the start of each key's run (advanced while scattering); dense, or a 64-byte
-                             // line per key when the batch has few keys (jjs_gpu.hip cursor_stride)
+                             // line per key when the batch has few keys (device_kernels.h cursor_stride)
 };
 
 // column `idx` (0 or 1) of K, chosen field by field: indexing the kernel-argument struct with a run-time index

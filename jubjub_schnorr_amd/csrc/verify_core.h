@@ -727,7 +727,7 @@ JJS_HD bool combined_subgroup_test(const eq_desc& E, uint64_t item, const half_s
 //  * per-item generator: PK and Gen get their own tests (own_test_mask); if the equation holds, R equals
 //    u*Gen + c*PK and is torsion-free with them; if it fails, R's test is pending.
 // The work of a verification is cut in two so that the device can run each half at the occupancy its
-// register needs allow (prepare_kernel: four waves per SIMD, verify_kernel: two; jjs_gpu.hip):
+// register needs allow (prepare_kernel: four waves per SIMD, verify_kernel: two; device_kernels.h):
 //   prepare_item : encodings, cheap point checks, own subgroup tests, challenge, half-size scalars, combined
 //                  subgroup tests -- everything except the window tables
 //   finish_item  : the equations and the verdict
@@ -747,7 +747,7 @@ JJS_HD bool keyed_mode(const verify_params& P) { return P.key_flag != nullptr &&
 // the first one runs (the keys are being counted beside it):
 //   PREP_HEAD  everything that does not depend on the decision: encodings of the transcript, the cheap checks of the points
 //              that are not keys, the challenge.  It does not read u at all (the challenge does not depend on it), so that
-//              a host-buffer call can send the u column last, behind everything the hashes need (jjs_gpu.hip
+//              a host-buffer call can send the u column last, behind everything the hashes need (host_calls.h
 //              run_host_block); the range check of u is made by whoever reads it next:
 //   PREP_TAIL  what only the throughput path needs (the launch leaves at once when the key tables engaged): u < r,
 //              validity of the key points, half-size scalars, combined subgroup tests; on the key-table path

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B timing of host-buffer piece plans on ONE box: builds variants of the library with other JJS_HOST_* knobs
-# (csrc/jjs_gpu.hip) HERE, before gpurun -- e.g.  bash scripts/host_ab.sh build v1 -DJJS_HOST_LEAD_SHARE_DEN=4 --
+# (csrc/host_calls.h) HERE, before gpurun -- e.g.  bash scripts/host_ab.sh build v1 -DJJS_HOST_LEAD_SHARE_DEN=4 --
 # and times them alternately there:  bash scripts/host_ab.sh run <scheme> <format> <rounds> v1 v2 ...
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = build ]; then

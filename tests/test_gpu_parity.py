@@ -535,7 +535,7 @@ def test_key_table_path_against_oracle(eng, scheme):
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
     assert set(want.tolist()) == {0, 1, 2, 3}
     # the blocking host-buffer entry points feed the same engine piece by piece (all columns of the first 2^16 items, then
-    # the key columns of all the others, then the rest: csrc/jjs_gpu.hip run_host_block): the batch three times over
+    # the key columns of all the others, then the rest: csrc/host_calls.h run_host_block): the batch three times over
     # (3 x 2^17 items, so that every kind of piece occurs), affine and extended coordinates, same statuses
     tiled = {k: np.concatenate([v, v, v]) for k, v in b.items()}
     want3 = np.concatenate([want, want, want])
@@ -720,7 +720,7 @@ def test_both_paths_at_every_size():
 @pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 16384), ("vargen", 16384), ("single", 4096), ("double", 4096),
                                           ("vargen", 4096)])
 def test_path_boundary(eng, scheme, limit):
-    """Either side of the sizes at which the product changes method (csrc/jjs_gpu.hip SMALL_PATH_FINE_ITEMS: 8 -> 4
+    """Either side of the sizes at which the product changes method (csrc/engine_state.h SMALL_PATH_FINE_ITEMS: 8 -> 4
     pieces on the latency path; SMALL_PATH_MAX_ITEMS: latency -> throughput path), against the oracle."""
     b = make_batch(scheme, limit + 1, seed=4711, n_keys=64)
     want = oracle_verify(scheme, b)
