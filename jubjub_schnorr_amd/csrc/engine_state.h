@@ -132,7 +132,7 @@ constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARG
 
 constexpr size_t HOST_MAX_PIECES = 40;      // pieces a host-buffer call uploads its block in (plan_pieces)
 #ifndef JJS_HOST_SIDE_STREAMS
-#define JJS_HOST_SIDE_STREAMS 3
+#define JJS_HOST_SIDE_STREAMS 2
 #endif
 constexpr int HOST_SIDE_STREAMS = JJS_HOST_SIDE_STREAMS;
 struct device_state {

@@ -4,17 +4,18 @@
 // Host-buffer calls.  The batch is cut into one contiguous block of ceil(n / devices) items per driven
 // device (the rule of jubjub_schnorr_amd/sharding.py) and every block is driven by its OWN host thread, so that
 // the uploads of different devices overlap (one thread issuing pageable copies for all devices would stage them
-// one after the other).  A block is ONE verification call on its device (verify_job), fed piece by piece: the thread
-// copies a piece of the caller's (pageable) arrays into one of two pinned staging slots -- with the help of the device's
-// staging threads, a single one moves ~11 GB/s -- queues its upload on the device's copy stream and, behind the upload,
-// whatever the piece makes possible: format conversion of its columns, the key kernels once every key has arrived, the
-// challenge hashes of the items whose columns are now complete.  The pieces of a block that may take the key tables come
-// in this order: all columns of a first few items (so that the hashes start at once), then the KEY columns of all the
-// others (the keys of the whole call are counted and tabled once, beside the hashes), then the remaining columns in
-// growing ranges.  The equations run once at the end, over the whole block, as in a resident call.  Device arena, pinned
-// staging and events are per device and only grow.  The tallies are summed over the devices with one RCCL all-reduce.
-// A failing block drains its streams before it reports, so nothing is in flight into the caller's or the library's
-// buffers when the call returns an error.
+// one after the other).  A block is ONE verification call on its device (verify_job), fed piece by piece: the device's
+// staging threads copy a piece of the caller's (pageable) arrays into one of three pinned staging slots (a single thread
+// moves ~11 GB/s), one piece ahead of the block's thread, which queues the piece's upload on the device's copy stream and,
+// behind the upload, whatever the piece makes possible: format conversion of its columns, the key kernels once every key
+// has arrived, the challenge hashes of the items whose hash inputs are now complete.  The pieces of a block that may take
+// the key tables come in this order (plan_pieces): the hash inputs of the first items (so that the hashes start at once),
+// in growing pieces up to half the block; the KEY columns of all the others (the keys of the whole call are counted and
+// tabled once, beside the hashes); their remaining hash inputs in growing ranges; and last the columns nothing reads
+// before the equations (u).  The equations run once at the end, over the whole block, as in a resident call.  Device
+// arena, pinned staging and events are per device and only grow.  The tallies are summed over the devices with one RCCL
+// all-reduce.  A failing block drains its streams before it reports, so nothing is in flight into the caller's or the
+// library's buffers when the call returns an error.
 struct host_col { const uint8_t* p; size_t width; uint32_t group; };      // group: COLS_KEYS, COLS_REST or COLS_LATE
 // build-time knobs of the A/B runs recorded in DESIGN.md 6 (scripts/host_ab.sh)
 #ifndef JJS_HOST_LEAD_LOG2
@@ -288,9 +289,11 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
     if (int rc = job_begin(J, g->stream)) return rc;
     // The ranges of the block are queued on several streams in turn: a launch waits for every block of its predecessor on
-    // the same stream, and a block of hashes lives for 1.4 ms, so on one stream (or two: scripts/host_timeline.sh) the chip
-    // runs half empty at the end of every range; with a stream per range in flight, whichever range has arrived fills the
-    // wave slots that come free.  The other streams start behind this one's job_begin (cleared flags and counters).
+    // the same stream, and a block of hashes lives for 1.4 ms, so on one stream the chip runs half empty at the end of
+    // every range; with a few streams, whichever range has arrived fills the wave slots that come free.  Three of them
+    // (this one and two more): for affine and wire inputs two to six measure the same, for extended inputs three are 0.7 ms
+    // ahead of four (profiles/r03_host_ab_streams*.jsonl).  The other streams start behind this one's job_begin (cleared
+    // flags and counters).
     HIP_TRY(hipEventRecord(g->host_begin, g->stream));
     hipStream_t compute[1 + HOST_SIDE_STREAMS] = {g->stream};
     for (int k = 0; k < HOST_SIDE_STREAMS; ++k) {
