@@ -109,12 +109,18 @@ struct host_block {
 //     latency-bound) and are wanted when the hashes end.  So: all columns of 2^16, 2^17, 2^18 ... items while that stays
 //     within half the block, then the key columns of the rest, then its remaining columns in ranges of 2^17, 2^18, 2^18 ...
 //     items (ranges of equal size keep the staging copy of the next range shorter than the upload of this one);
-//   * a wire call hashes nothing before its keys are decoded (keys_gate_hashes): its key column goes first, whole.
+//   * a wire call (wire_points: R points per signature) decodes each distinct key once, which takes the whole key column.
+//     With one R point per signature the plan is the one above, and the ranges that travel ahead of the rest's key columns
+//     decode the keys of their own items instead (a square root per item: 0.75 ms of arithmetic for the 7/16 of a 2^20-item
+//     block that they are, done while the chip would wait for the bus).  With two (double signatures: 4 ms of square roots,
+//     more than their upload takes) the key columns travel LAST, whole: the R points are decoded at the pace of the bus with
+//     nothing else on the chip, and every range is hashed behind the key kernels' decoding.  Measured, single / double calls of
+//     2^20 items: key columns first 13.8 / 24.0 ms, last 13.7 / 21.7, the plan above 13.4 / 24.3 (profiles/r03_host_ab_wire_plan.jsonl).
 //   * the columns nothing reads before the equations (u) travel last, behind everything the hashes need, when the call
 //     hashes with the head launch (`late`: 16 % fewer bytes ahead of the first hashes of a single batch); else with the others.
 // row_keys / row_rest / row_late: bytes per item of the column groups.
 void plan_pieces(std::vector<host_piece>& pieces, size_t& largest_bytes, size_t nl, size_t row_keys, size_t row_rest, size_t row_late,
-                 bool keys_gate_hashes, bool late) {
+                 int wire_points, bool late) {
     pieces.clear();
     const uint32_t rest = COLS_REST | (late ? 0u : COLS_LATE);       // the groups that travel as "the other columns"
     auto add = [&](size_t first, size_t count, uint32_t cols) {
@@ -142,17 +148,30 @@ void plan_pieces(std::vector<host_piece>& pieces, size_t& largest_bytes, size_t 
     if (!keys_first) {
         ranges(0, HOST_LEAD_ITEMS, 4, cap_rest, COLS_KEYS | rest);
     } else {
-        size_t lead = 0;
-        if (!keys_gate_hashes) {
-            size_t next = HOST_LEAD_ITEMS;
+        bool keys_last = wire_points >= 2;
+#if defined(JJS_HOST_WIRE_KEYS_LAST)       // build-time knobs of the A/B run recorded in DESIGN.md 6
+        keys_last = wire_points >= 1;
+#elif defined(JJS_HOST_WIRE_KEYS_LEAD) || defined(JJS_HOST_WIRE_KEYS_FIRST)
+        keys_last = false;
+#endif
+        if (keys_last) {
+            ranges(0, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, rest);
+            ranges(0, cap_keys, 1, cap_keys, COLS_KEYS);
+#if defined(JJS_HOST_WIRE_KEYS_FIRST)
+        } else if (wire_points) {
+            ranges(0, cap_keys, 1, cap_keys, COLS_KEYS);
+            ranges(0, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, rest);
+#endif
+        } else {
+            size_t lead = 0, next = HOST_LEAD_ITEMS;
             do {
                 add(lead, next, COLS_KEYS | rest);
                 lead += next;
                 next = next * 2 < cap_rest ? next * 2 : cap_rest;
             } while (lead + next <= nl / HOST_LEAD_SHARE_DEN * HOST_LEAD_SHARE_NUM);
+            ranges(lead, cap_keys, 1, cap_keys, COLS_KEYS);
+            ranges(lead, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, rest);
         }
-        ranges(lead, cap_keys, 1, cap_keys, COLS_KEYS);
-        ranges(lead, HOST_REST_ITEMS_FIRST, HOST_REST_GROWTH, cap_rest, rest);
     }
     if (late && row_late) ranges(0, cap_keys, 1, cap_keys, COLS_LATE);
 }
@@ -301,21 +320,29 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         compute[1 + k] = g->side[k];
     }
     constexpr size_t NCS = 1 + HOST_SIDE_STREAMS;
+    size_t hash_items[NCS] = {};                        // items whose hashes have been queued on compute[k]
     hipStream_t converted_on[HOST_MAX_PIECES] = {};     // the stream a piece's columns were converted on (job_ingest)
     size_t last_key_piece = np;                         // the piece whose arrival completes the key columns
     for (size_t i = 0; i < np; ++i)
         if (b.pieces[i].cols & COLS_KEYS) last_key_piece = i;
     struct deferred { size_t first, count; hipStream_t cs; };
-    // ranges whose hashes cannot be queued yet: a wire call hashes behind its key kernels; and a call that was expected to
-    // hash with the head launch but does not after all (job_begin could not set the key tables up) reads u, which then
-    // travels last
+    // ranges whose hashes cannot be queued yet: a call that was expected to hash with the head launch but does not after
+    // all (job_begin could not set the key tables up) reads u, which then travels last; and ranges whose key columns travel
+    // behind them (wire calls of double signatures)
     std::vector<deferred> waiting;
     const bool needs_late = late && !J.split;
     size_t last_late_piece = np;
     for (size_t i = 0; i < np; ++i)
         if (b.pieces[i].cols & COLS_LATE) last_late_piece = i;
+    // key columns that travel behind the other columns of their items (wire calls): nothing of those items is hashed before
+    bool keys_trail = false;
+    for (size_t i = 0; i < np; ++i)
+        for (size_t j = i + 1; j < np; ++j) {
+            const host_piece &a = b.pieces[i], &k = b.pieces[j];
+            keys_trail = keys_trail || ((a.cols & COLS_REST) && (k.cols & COLS_KEYS) && k.first < a.first + a.count && a.first < k.first + k.count);
+        }
     auto hashes_blocked = [&](size_t i) {
-        return (job_hash_needs_keys(J) && !J.keys_queued) || (needs_late && i < last_late_piece);
+        return (needs_late && i < last_late_piece) || (keys_trail && i < last_key_piece);
     };
     for (size_t i = 0; i < np; ++i) {
         const host_piece& pc = b.pieces[i];
@@ -346,8 +373,14 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
 #if defined(JJS_PROFILING)
         if (i == 0) t_first = now() - t_begin;
 #endif
-        hipStream_t cs = compute[i % NCS];
-        if (i % NCS) J.side[i % NCS - 1] = cs;
+        // the stream with the fewest items to hash queued on it so far (in turn, they leave a short last range behind the
+        // longest one: a wire call's last 2^17 items hashed alone for 0.8 ms, scripts/host_timeline.sh)
+        size_t pick = 0;
+        for (size_t k = 1; k < NCS; ++k)
+            if (hash_items[k] < hash_items[pick]) pick = k;
+        if (pc.cols & COLS_REST) hash_items[pick] += pc.count;
+        hipStream_t cs = compute[pick];
+        if (pick) J.side[pick - 1] = cs;
         // Extended points are normalised on a stream of higher priority than the hashes: that kernel is a few waves with a
         // long dependent chain (one inversion per lane), its piece cannot be hashed before it ends, and behind the hashes of
         // the pieces before it it waited 0.8-1.2 ms for wave slots instead of running 0.25 (scripts/host_timeline.sh).
@@ -367,6 +400,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         if (!waiting.empty() && !hashes_blocked(i)) {
             for (const deferred& d : waiting) {
                 if (needs_late) HIP_TRY(hipStreamWaitEvent(d.cs, g->chunk_up[last_late_piece], 0));
+                if (keys_trail) HIP_TRY(hipStreamWaitEvent(d.cs, g->chunk_done[last_key_piece], 0));
                 if (int rc = job_hash(J, d.first, d.count, d.cs)) return rc;
             }
             waiting.clear();
@@ -404,7 +438,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     return JJS_OK;
 }
 
-int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, bool keys_gate_hashes) {
+int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, int wire_points) {
     if (n_cols > 8) return fail(JJS_ERR_ARG, "internal: too many columns");
     for (size_t k = 0; k < n_cols; ++k)
         if (n && !cols[k].p) return fail(JJS_ERR_ARG, "null input pointer");
@@ -432,8 +466,8 @@ int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uin
         b.lo = d * per < n ? d * per : n;
         b.hi = b.lo + per < n ? b.lo + per : n;
         b.largest_bytes = 256;
-        plan_pieces(b.plans[0], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, keys_gate_hashes, false);
-        plan_pieces(b.plans[1], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, keys_gate_hashes, true);
+        plan_pieces(b.plans[0], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, wire_points, false);
+        plan_pieces(b.plans[1], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, wire_points, true);
         b.staging_threads = staging_threads;
     }
     auto work = [&](size_t d) {

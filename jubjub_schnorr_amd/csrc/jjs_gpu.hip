@@ -508,10 +508,10 @@ static int resident_call(call_builder build, const void* const* d, size_t n, voi
 }
 // a host-buffer call: blocking
 static int host_call(call_builder build, const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4],
-                     bool keys_gate_hashes = false) {
+                     int wire_points = 0) {
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    return no_throw([&] { return run_host(cols, n_cols, n, status, tally, build, keys_gate_hashes); });
+    return no_throw([&] { return run_host(cols, n_cols, n, status, tally, build, wire_points); });
 }
 
 // ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
@@ -561,15 +561,15 @@ int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, s
 }
 int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
     const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 32, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_single, cols, 3, n, status, tally, true);
+    return host_call(build_wire_single, cols, 3, n, status, tally, 1);
 }
 int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
     const host_col cols[] = {{sig, 96, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_double, cols, 3, n, status, tally, true);
+    return host_call(build_wire_double, cols, 3, n, status, tally, 2);
 }
 int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
     const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_vargen, cols, 3, n, status, tally, true);
+    return host_call(build_wire_vargen, cols, 3, n, status, tally, 1);
 }
 
 // ---- extended coordinates (U, V, Z): normalised on the device, then the same verify kernels -----------------

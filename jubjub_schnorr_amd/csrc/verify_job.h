@@ -351,8 +351,6 @@ int job_keys(verify_job& J) {
     J.keys_queued = true;
     return JJS_OK;
 }
-// a wire call that tries the key tables can hash only after job_keys (it waits for the decoded keys)
-bool job_hash_needs_keys(const verify_job& J) { return J.C.wire && J.try_keys; }
 
 // The items [first, first + count) have all their columns in place and ingested: hash them.
 int job_hash(verify_job& J, uint64_t first, uint64_t count, hipStream_t cs) {
@@ -365,8 +363,7 @@ int job_hash(verify_job& J, uint64_t first, uint64_t count, hipStream_t cs) {
         return launch_small(P, cs);
     }
     if (J.C.wire) {
-        if (J.try_keys) {
-            if (!J.keys_queued) return fail(JJS_ERR_ARG, "internal: wire hashes before the key kernels");
+        if (J.try_keys && J.keys_queued) {
             HIP_TRY(hipStreamWaitEvent(cs, sl->key_mid, 0));
             // this stream decodes the key columns item by item only if the batch turned the key tables down; else every
             // item fetches its key's point

@@ -10,7 +10,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [HERE, os.path.join(HERE, "..", "oracle"), os.path.join(HERE, "..")]
 
-from helpers import ARG_ORDER, edge_cases, make_batch, oracle_verify, torsion_grid  # noqa: E402
+from helpers import ARG_ORDER, edge_cases, make_batch, oracle_verify, to_wire, torsion_grid  # noqa: E402
 
 
 def main() -> None:
@@ -61,6 +61,14 @@ def main() -> None:
         after = eng.path_stats()
         assert after["throughput"] == before["throughput"] + 2, (before, after)
         assert after["key_tables_wide"] + after["key_tables_narrow"] == before["key_tables_wide"] + before["key_tables_narrow"]
+        # the wire form from host buffers, three times over (double signatures: the key columns travel behind the signatures):
+        # without the key kernels every range decodes its own keys, once they have arrived
+        w3 = [np.concatenate([a, a, a]) for a in to_wire(scheme, b)]
+        assert lib.jjs_debug_fail_key_arena(1) == 0
+        st_w, tally_w = eng.verify_wire(scheme, *w3)
+        assert lib.jjs_debug_fail_key_arena(0) == 0
+        assert (st_w == np.concatenate([want, want, want])).all(), scheme
+        assert eng.path_stats()["throughput"] == after["throughput"] + 1
     # keys crafted to collide in the dedup table: harmless under the per-call seed of the product; with the seed pinned
     # (what the sender would need to know) the probe limit sends the batch down the throughput path, statuses unchanged
     from helpers import crafted_collision_batch

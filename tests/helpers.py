@@ -328,3 +328,14 @@ def crafted_collision_batch(n_good=1 << 17, n_bad=2000):
         assert (h & 0xFFFFFFFF) & mask == target
         b["PK"][i] = np.frombuffer(key, np.uint8)
     return b
+
+
+def to_wire(scheme, b):
+    """The reference's byte formats of a batch: (signature bytes, key bytes, messages)."""
+    comp = lambda a: np.stack([np.frombuffer(o.compress((int.from_bytes(r[:32].tobytes(), "little"),  # noqa: E731
+                                                         int.from_bytes(r[32:].tobytes(), "little"))), np.uint8) for r in a])
+    if scheme == "single":
+        return np.concatenate([b["u"], comp(b["R"])], 1), comp(b["PK"]), b["m"]
+    if scheme == "double":
+        return np.concatenate([b["u"], comp(b["R"]), comp(b["Rp"])], 1), np.concatenate([comp(b["PK"]), comp(b["PKp"])], 1), b["m"]
+    return np.concatenate([b["u"], comp(b["R"])], 1), np.concatenate([comp(b["PK"]), comp(b["Gen"])], 1), b["m"]

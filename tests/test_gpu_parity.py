@@ -8,7 +8,7 @@ import pytest
 
 import jjs_oracle as o
 import jjs_oracle_c as oc
-from helpers import (ARG_ORDER, batch_to_extended, edge_cases, ext_on_device, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
+from helpers import (ARG_ORDER, to_wire, batch_to_extended, edge_cases, ext_on_device, fe_bytes, make_batch, oracle_verify, pt_arr, rand_mod, to_int, torsion_generator,
                      torsion_grid)
 
 pytestmark = pytest.mark.gpu
@@ -380,16 +380,6 @@ def test_decompress_and_compress(eng):
     assert [r.tobytes() for r in back] == [enc[i] for i in good]
 
 
-def to_wire(scheme, b):
-    comp = lambda a: np.stack([np.frombuffer(o.compress((int.from_bytes(r[:32].tobytes(), "little"),  # noqa: E731
-                                                         int.from_bytes(r[32:].tobytes(), "little"))), np.uint8) for r in a])
-    if scheme == "single":
-        return np.concatenate([b["u"], comp(b["R"])], 1), comp(b["PK"]), b["m"]
-    if scheme == "double":
-        return np.concatenate([b["u"], comp(b["R"]), comp(b["Rp"])], 1), np.concatenate([comp(b["PK"]), comp(b["PKp"])], 1), b["m"]
-    return np.concatenate([b["u"], comp(b["R"])], 1), np.concatenate([comp(b["PK"]), comp(b["Gen"])], 1), b["m"]
-
-
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
 @pytest.mark.parametrize("n", [1, 65, 600])
 def test_verify_wire(eng, scheme, n):
@@ -607,7 +597,8 @@ def test_key_table_path_wire_against_oracle(eng, scheme):
     assert (got == want).all(), np.where(got != want)[0][:10]
     assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
     assert set(want.tolist()) == {0, 1, 2, 3} and (want[negated] != 0).all()
-    # host buffers, the batch three times over: the key column travels first, the keys are decoded once for the whole call
+    # host buffers, the batch three times over: the first ranges decode the keys of their own items, the others fetch their
+    # key's point, decoded once for the whole call (double signatures: the key columns travel last and every range fetches)
     want3 = np.concatenate([want, want, want])
     st_h, tally_h = eng.verify_wire(scheme, *[np.concatenate([a, a, a]) for a in (sig, pk, m)])
     assert (st_h == want3).all(), np.where(st_h != want3)[0][:10]
