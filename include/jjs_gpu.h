@@ -49,8 +49,9 @@
  *
  * Method: the engine picks, per call, from the batch size and the repetition of its keys alone (no configuration):
  * at most 16 384 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
- * ~0.85 ms var-generator up to 4 096 items); larger -> one signature per lane; at least 65 536 items whose public
- * keys (and per-item generators) repeat 16 times or more on average -> per-key tables built inside the call.  The
+ * ~0.85 ms var-generator up to 4 096 items); larger -> one signature per lane; at least 65 536 items (32 768 for double
+ * and var-generator signatures) whose public keys (and per-item generators) repeat 16 times or more on average ->
+ * per-key tables built inside the call.  The
  * status bytes are the same on every path.
  */
 #ifndef JJS_GPU_H

@@ -131,11 +131,23 @@ __global__ __launch_bounds__(BLOCK) void key_spread_kernel(key_params K) {
             if (r != (uint32_t)item) C.keyid[item] = C.keyid[r];      // r's own id was written by the previous launch
         }
 }
+// The chain of bases and `is_valid` of every key.  One lane per key does both (kt_chain_key); where the batch waits for the
+// chains (K.quad_chains, set by job_keys) four lanes per key share the doublings (kt_chain_key_quad) and a fifth runs
+// `is_valid`: the grid covers 5 x n_cols x max_keys lanes then.
 __global__ __launch_bounds__(BLOCK, 2) void key_chain_kernel(key_params K) {
     const int w = (int)K.counters[2];
     if (!w) return;
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, c = t / K.max_keys, id = t % K.max_keys;
-    if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id, w);
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, keys = K.n_cols * K.max_keys;
+    if (!K.quad_chains) {
+        const uint32_t c = t / K.max_keys, id = t % K.max_keys;
+        if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id, w);
+    } else if (t < 4 * keys) {
+        const uint32_t q = t >> 2, c = q / K.max_keys, id = q % K.max_keys;          // the same for the four lanes of a quad
+        if (id < K.counters[c]) kt_chain_key_quad(kt_col(K, (int32_t)c), id, w, t & 3u);
+    } else if (t < 5 * keys) {
+        const uint32_t q = t - 4 * keys, c = q / K.max_keys, id = q % K.max_keys;
+        if (id < K.counters[c]) kt_key_flags(kt_col(K, (int32_t)c), id);
+    }
 }
 // the grid covers max_keys x KT_MAX_POSITIONS lanes per column; a batch with wide windows has fewer of both
 __global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {

@@ -101,10 +101,11 @@ struct call_slot {
     size_t key_pool_refused = 0;      // a size hipMalloc turned down (not asked for again)
     key_feedback* seen = nullptr;     // pinned host memory
     bool seen_pending = false;        // `seen` is being written by a call that may still run (its end: last_use)
+    bool keys_repeated = true;        // the slot's last key-table attempt that has ended built tables (launch_staged)
     uint64_t seen_n = 0;              // ... whose batch had this many items in
     uint32_t seen_cols = 0;           // ... this many key columns
     hipStream_t key_stream = nullptr; // the per-key kernels of the slot's call run here, beside the challenge hashes
-    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr;
+    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr, key_ahead = nullptr;
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
     hipStream_t last_stream = nullptr;// ... and the stream it was issued on
 };
@@ -130,7 +131,7 @@ constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
 constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
-constexpr size_t HOST_MAX_PIECES = 40;      // pieces a host-buffer call uploads its block in (plan_pieces)
+constexpr size_t HOST_MAX_PIECES = 64;      // pieces a host-buffer call uploads its block in (plan_pieces)
 #ifndef JJS_HOST_SIDE_STREAMS
 #define JJS_HOST_SIDE_STREAMS 2
 #endif

@@ -132,6 +132,7 @@ int init_device(device_state& d, int ordinal) {
             HIP_TRY(hipEventCreateWithFlags(&c.key_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_mid, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_join, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_ahead, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.seen), sizeof(key_feedback), hipHostMallocDefault));
             memset(c.seen, 0, sizeof(key_feedback));
         }
@@ -178,7 +179,7 @@ void free_device(device_state& d) {
         for (void* b : sb)
             if (b) (void)hipFree(b);
         if (c.seen) (void)hipHostFree(c.seen);
-        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join};
+        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join, c.key_ahead};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }

@@ -83,7 +83,7 @@ struct key_params {
     uint32_t max_keys;       // keys per column whose narrow-window tables fit the slot's table pool (also the bound of the ids
                              // that get a representative item); max_keys_wide: the same for wide windows
     uint32_t max_keys_wide;
-    uint32_t pad_;
+    uint32_t quad_chains;    // the chain of a key on four lanes (kt_chain_key_quad) instead of one: where the batch waits for the chains
     uint64_t seed;           // per-call seed of the dedup hash (kt_hash)
     key_column col[2];
     uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 0 = throughput path, else the window width of
@@ -195,6 +195,73 @@ JJS_HD void kt_chain_key(const key_column& C, uint32_t id, int w) {
         for (int j = 0; j < w; ++j) p = ext_double(p, j == w - 1);
         kt_store_ext(kt_base(C, id, pos, w), p);
     }
+}
+
+#if defined(__HIPCC__)
+// The same chain on FOUR adjacent lanes per key (a quad: DPP quad_perm reaches its lanes without LDS).  A doubling is two
+// rounds of four independent products; lane j computes product j of each round and the results are broadcast in the quad,
+// so the critical path of a doubling is two products instead of seven, plus 72 register moves: the chain is 252 doublings
+// long whatever the batch, and batches of up to 2^18 items wait for it.  Same products on the same limbs as
+// ext_double (a square is the product of a value with itself, limb for limb), so the bases are bit-identical.
+template <int K>
+__device__ __forceinline__ fe_n quad_bcast(const fe_n& v) {
+    fe_n r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], K * 0x55, 0xf, 0xf, true);
+#else
+        r.l[i] = v.l[i];          // host pass of the compiler: never executed
+#endif
+    }
+    return r;
+}
+// 2P on the quad's four lanes (j = lane within the quad); every lane holds P and gets 2P.  `own` = this lane's product of
+// the second round: coordinate j of 2P (X, Y, Z, T).
+__device__ __forceinline__ ext_pt ext_double_quad(const ext_pt& p, uint32_t j, fe_n& own) {
+    const bool j0 = j == 0, j1 = j == 1, j2 = j == 2, j3 = j == 3;
+    const fe_n a = fq_select(j0 || j1, p.x, fq_select(j2, p.y, p.z));       // X X Y Z
+    const fe_n b = fq_select(j0, p.y, a);                                    // Y X Y Z
+    const fe_n m = fq_mul_hot(a, b);
+    const fe_n xy = quad_bcast<0>(m), xx = quad_bcast<1>(m), yy = quad_bcast<2>(m), zz = quad_bcast<3>(m);
+    auto e = fq_dbl(xy);                           // 2XY             <2,4>
+    auto c2 = fq_dbl(zz);                          // 2Z^2            <2,4>
+    auto g = fq_norm(fq_add(yy, xx));          // <1,4>
+    auto h = fq_sub(yy, xx);                   // <3,5>
+    auto f = fq_norm(fq_sub(fq_add(c2, xx), yy));   // <1,9>
+    // X3 = f e, Y3 = g h, Z3 = f h, T3 = g e: the first factors are f or g (normalised, < 9q), the second e or h
+    const fe<1, 9> a2 = fq_select(j0 || j2, f, fq_as<1, 9>(g));
+    const fe<3, 5> b2 = fq_select(j0 || j3, fq_as<3, 5>(e), h);
+    own = fq_mul_hot(a2, b2);
+    ext_pt r;
+    r.x = quad_bcast<0>(own); r.y = quad_bcast<1>(own); r.z = quad_bcast<2>(own); r.t = quad_bcast<3>(own);
+    return r;
+}
+// the chain of bases of one key on a quad (kt_chain_key without the validity test, which other lanes run: kt_key_flags)
+__device__ __forceinline__ void kt_chain_key_quad(const key_column& C, uint32_t id, int w, uint32_t j) {
+    const uint64_t item = C.key_item[id];
+    const fe_n pu = fq_from_words(load_words(C.src, item)), pv = fq_from_words(load_words(C.src, item, 32));
+    ext_pt p = ext_from_affine(pu, pv);
+    if (j == 0) kt_store_ext(kt_base(C, id, 0, w), p);
+    const uint32_t positions = (uint32_t)kt_positions(w);
+    for (uint32_t pos = 1; pos < positions; ++pos) {
+        fe_n own;
+#pragma unroll 1
+        for (int k = 0; k < w; ++k) p = ext_double_quad(p, j, own);
+        uint32_t* dst = kt_base(C, id, pos, w) + 9 * j;           // lane j holds coordinate j of the new base
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[i] = own.l[i];
+    }
+}
+#endif
+// `is_valid` of one key's point (the other half of kt_chain_key)
+JJS_HD void kt_key_flags(const key_column& C, uint32_t id) {
+    const uint64_t item = C.key_item[id];
+    const words8 uw = load_words(C.src, item), vw = load_words(C.src, item, 32);
+    const bool canonical = words_lt(uw, JJS_Q_WORDS) && words_lt(vw, JJS_Q_WORDS);
+    const fe_n pu = fq_from_words(uw), pv = fq_from_words(vw);
+    const bool valid = canonical && point_on_curve_not_identity(pu, pv) && is_torsion_free(pu, pv);
+    C.key_flags[id] = (uint8_t)((canonical ? 0u : KT_KEY_MALFORMED) | (valid ? KT_KEY_VALID : 0u));
 }
 
 // table[j] = j * P for j = 0 .. entries-1, P in extended coordinates (the cached-addend entries keep their Z)

@@ -3,8 +3,11 @@
 // host-buffer call feeds range by range (host_calls.h).
 #pragma once
 // ---- key-table path: arenas ------------------------------------------------------------------------------
-// Batches of at least this many items (big or medium slot) try the key tables.
-constexpr size_t KT_MIN_ITEMS = 65536;
+// Batches of at least this many items (big or medium slot) try the key tables: single signatures from 65 536 items on; the
+// schemes with two table lookups per item (double signatures, per-item generators), whose throughput path is two equations
+// or full-size scalars, from 32 768 (2^15 items under 1 024 keys: double 2.64 -> 2.28 ms, var-gen 2.23 -> 1.96, single
+// 1.57 -> 1.70; profiles/r03_quad_chain_ab.txt).
+constexpr size_t KT_MIN_ITEMS = 65536, KT_MIN_ITEMS_TWO_LOOKUPS = 32768;
 // The table pool a slot starts with: SURVEY.md 8(d)'s 4 096 keys with wide windows are 0.86 GB per column, two columns
 // (double, var-gen) 1.73 GB.  A call whose keys repeat but need more leaves a note (key_feedback) and the pool has grown
 // by the slot's next call; until then the call runs the throughput path, as it would with keys that do not repeat.
@@ -51,6 +54,7 @@ void note_key_feedback() {
     if (!sl->seen_pending || hipEventQuery(sl->last_use) != hipSuccess) return;
     sl->seen_pending = false;
     const uint32_t* c = sl->seen->counters;
+    sl->keys_repeated = c[2] != 0;
     if (c[2] == (uint32_t)KT_WINDOW_WIDE) ++g->stats[JJS_PATH_KEY_TABLES_WIDE];
     else if (c[2] == (uint32_t)KT_WINDOW_NARROW) ++g->stats[JJS_PATH_KEY_TABLES_NARROW];
     else if (c[3]) ++g->stats[JJS_PATH_KEYS_PROBE_LIMIT];
@@ -108,7 +112,9 @@ bool key_path_applies(const verify_params& P) {
 #if defined(JJS_PROFILING)
     if (g_force_path == 3) return false;           // throughput path without the key tables
 #endif
-    return P.n >= KT_MIN_ITEMS && P.n <= 0x7fffffffu && P.n_eq >= 1 && sl->key_stream != nullptr;
+    if (P.n_eq < 1) return false;
+    const bool one_lookup = P.n_eq == 1 && P.eq[0].comb != nullptr;          // single signatures: c * PK only
+    return P.n >= (one_lookup ? KT_MIN_ITEMS : KT_MIN_ITEMS_TWO_LOOKUPS) && P.n <= 0x7fffffffu && sl->key_stream != nullptr;
 }
 // The compressed key columns of a wire call: decoded once per key when the key tables engage and once per item
 // otherwise, into the affine columns the scheme descriptor already points at.
@@ -317,6 +323,7 @@ int job_ingest(verify_job& J, uint64_t first, uint64_t count, uint32_t cols, hip
     return JJS_OK;
 }
 
+constexpr uint64_t KEYS_AHEAD_MAX_ITEMS = 1u << 18;      // see launch_staged
 // Every key column of the call is in place (on the key stream's timeline: the caller has made it wait for whatever
 // put them there): count the distinct keys, decide on the device, build the per-key tables.
 int job_keys(verify_job& J) {
@@ -325,6 +332,15 @@ int job_keys(verify_job& J) {
     key_params& K = J.K;
     hipStream_t ks = sl->key_stream;
     const unsigned item_blocks = (unsigned)grid_for(8192, P.n);
+    // Four lanes per key for the chains (a third of the latency, twice the instructions) where the batch waits for them: up to
+    // 2^18 items, and with two key columns, whose key kernels take twice as long and end after the hashes of a 2^20 batch
+    // (var-gen 12.36 -> 11.94 ms, double unchanged; a single 2^20 batch does not wait for its chains and is 1 % slower
+    // with them on four lanes: profiles/r03_quad_chain_ab.txt)
+#if defined(JJS_AB_CHAIN_ONE_LANE)        // build-time knob of the A/B run recorded in DESIGN.md 6
+    K.quad_chains = 0;
+#else
+    K.quad_chains = (P.n <= KEYS_AHEAD_MAX_ITEMS || K.n_cols >= 2) ? 1u : 0u;
+#endif
     J.Kd = K;                                   // a wire call deduplicates the 32-byte encodings
     if (J.C.wire)
         for (uint32_t c = 0; c < K.n_cols; ++c) { J.Kd.col[c].src = J.C.W.comp[c]; J.Kd.col[c].key_bytes = 32; }
@@ -343,7 +359,8 @@ int job_keys(verify_job& J) {
     hipLaunchKernelGGL(key_count_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, K);
     hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(1024), 0, ks, K);
     hipLaunchKernelGGL(key_scatter_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, K);
-    hipLaunchKernelGGL(key_chain_kernel, dim3(key_blocks), dim3(BLOCK), 0, ks, K);
+    HIP_TRY(hipEventRecord(sl->key_ahead, ks));                // the keys are counted and grouped: see launch_staged
+    hipLaunchKernelGGL(key_chain_kernel, dim3(((K.quad_chains ? 5 : 1) * K.n_cols * K.max_keys + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ks, K);
     hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
                        dim3(BLOCK), 0, ks, K);
     HIP_TRY(hipGetLastError());
@@ -429,6 +446,20 @@ int launch_staged(const staged_call& C, hipStream_t s) {
                  ? JJS_OK : fail(JJS_ERR_HIP, "event between the caller's stream and the key stream");
     }
     if (!rc) rc = job_keys(J);
+    // A batch of up to 2^18 items -- one generation of prepare_kernel's blocks -- hashes only once its keys are counted and
+    // grouped (0.13-0.22 ms on the empty chip), so that the per-key chains (252 dependent doublings: 1.05 ms whatever the
+    // batch) start with the hashes.  Launched beside them, the key kernels waited for the first wave slot to come free (the
+    // blocks of prepare_kernel hold theirs for 1.5 ms) and the tables were ready 1.0 ms after the hashes: 2^18 items 3.55 ->
+    // 3.05 ms single, 5.6 -> 4.9 double, 4.5 -> 3.85 var-gen; 2^17: 2.84 -> 2.79, 4.0 -> 3.82, 3.44 -> 3.27
+    // (profiles/r03_keys_ahead_ab.txt, r03_timeline_medium.txt).  At 2^19 items the hashes outlast the key kernels
+    // either way and double batches lose 0.4 ms by waiting: larger batches start at once.  A batch whose keys turn out not to
+    // repeat has waited for nothing (0.25 ms at 2^18): the slot remembers how its last attempt that has ended came out, and
+    // after one that built no tables the hashes start at once (a caller who queues batch after batch without waiting for
+    // any gives the slot nothing to remember).
+#if !defined(JJS_AB_NO_KEYS_AHEAD)        // build-time knob of the A/B run recorded in DESIGN.md 6
+    if (!rc && J.try_keys && J.keys_queued && C.P.n <= KEYS_AHEAD_MAX_ITEMS && sl->keys_repeated)
+        rc = hipStreamWaitEvent(s, sl->key_ahead, 0) == hipSuccess ? JJS_OK : fail(JJS_ERR_HIP, "event between the key stream and the caller's stream");
+#endif
     if (!rc) rc = job_hash(J, 0, C.P.n, s);
     if (!rc) rc = job_finish(J);
     if (rc) job_abandon(J);
