@@ -117,7 +117,7 @@ class Engine:
             ptrs = [self._dev_ptr(a, w, n) for a, w in zip(arrays, widths)]
             dev = arrays[0].device
             status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)[:n] if want_status else None
-            tally = torch.zeros(4, dtype=torch.int64, device=dev)
+            tally = torch.empty(4, dtype=torch.int64, device=dev)          # the call clears it (one launch fewer than torch.zeros)
             fn = getattr(self._lib, f"jjs_verify_{scheme}{suffix}_dev")
             _ffi.check(fn(*ptrs, n, ctypes.c_void_p(status.data_ptr()) if want_status and n else None,
                           ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}{suffix}_dev")
@@ -162,7 +162,7 @@ class Engine:
         n = sig.shape[0]
         ptrs = [self._dev_ptr(sig, ws, n), self._dev_ptr(pk, wp, n), self._dev_ptr(m, wm, n)]
         status = torch.empty(max(n, 1), dtype=torch.uint8, device=sig.device)[:n] if want_status else None
-        tally = torch.zeros(4, dtype=torch.int64, device=sig.device)
+        tally = torch.empty(4, dtype=torch.int64, device=sig.device)
         fn = getattr(self._lib, f"jjs_verify_{scheme}_wire_dev")
         _ffi.check(fn(*ptrs, n, ctypes.c_void_p(status.data_ptr()) if want_status and n else None,
                       ctypes.c_void_p(tally.data_ptr()), self._stream()), f"jjs_verify_{scheme}_wire_dev")

@@ -60,6 +60,28 @@ __global__ __launch_bounds__(BLOCK, 2) void verify_kernel(verify_params P) {
 }
 
 // ---- key-table path (key_tables.h) ---------------------------------------------------------------------
+// What a call finds cleared on its own stream (counters of the caller, the queue of the resolve pass, the flags of a wire or
+// ext call), in ONE launch instead of one fill each: every small dependent launch at the head of a call is 15-50 us.
+struct clear_params {
+    void* p[3];
+    uint64_t bytes[3];
+};
+__global__ __launch_bounds__(BLOCK) void clear_kernel(clear_params C) {
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x, total = (uint64_t)gridDim.x * BLOCK;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint8_t* const p = static_cast<uint8_t*>(C.p[k]);
+        const uint64_t bytes = C.bytes[k];
+        if (!p || !bytes) continue;
+        const uint64_t head = (uint64_t)(-(intptr_t)p & 15) < bytes ? (uint64_t)(-(intptr_t)p & 15) : bytes;     // up to 16-byte alignment
+        const uint64_t body = (bytes - head) / 16;
+        uint4* const q = reinterpret_cast<uint4*>(p + head);
+        for (uint64_t i = t; i < body; i += total) q[i] = uint4{0u, 0u, 0u, 0u};
+        const uint64_t tail0 = head + body * 16;
+        for (uint64_t i = t; i < head; i += total) p[i] = 0;
+        for (uint64_t i = tail0 + t; i < bytes; i += total) p[i] = 0;
+    }
+}
 __global__ __launch_bounds__(BLOCK) void key_dedup_kernel(key_params K) {
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t item = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; item < K.n; item += total) {

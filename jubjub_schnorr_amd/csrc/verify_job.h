@@ -165,17 +165,20 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     const size_t order_bytes = pad256(P.n * 4) + pad256(cursor_words * 4);
     if (int rc = ensure_key_index(256 + order_bytes + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
+    // what every call finds cleared comes first and side by side (one memset, one launch: the dozen small dependent launches at
+    // the head of a call are a third of a 2^16-item batch): counters, cursors, the hash table of every column
+    uint8_t* const cleared = p;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
-    HIP_TRY(hipMemsetAsync(K.counters, 0, 256, s));
-    K.order = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
     K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad256(cursor_words * 4);
-    HIP_TRY(hipMemsetAsync(K.key_cursor, 0, cursor_words * 4, s));
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        K.col[c].hash = reinterpret_cast<uint32_t*>(p); K.col[c].hash_mask = (uint32_t)(slots - 1); p += pad256(slots * 4);
+    }
+    HIP_TRY(hipMemsetAsync(cleared, 0, (size_t)(p - cleared), s));
+    K.order = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
         C.src = cols[c];
         C.key_bytes = 64;
-        C.hash = reinterpret_cast<uint32_t*>(p); C.hash_mask = (uint32_t)(slots - 1); p += pad256(slots * 4);
-        HIP_TRY(hipMemsetAsync(C.hash, 0, slots * 4, s));
         C.rep = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
         C.keyid = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
         uint8_t* q = sl->key_pool + (size_t)c * col_bytes;
@@ -275,14 +278,22 @@ int job_begin(verify_job& J, hipStream_t s) {
     P.workspace = sl->workspace;
     if (int rc = begin_shared(s)) return rc;
     J.open = true;
-    if (P.tally) HIP_TRY(hipMemsetAsync(P.tally, 0, 4 * sizeof(unsigned long long), s));
-    if (P.pre_malformed) HIP_TRY(hipMemsetAsync(const_cast<uint8_t*>(P.pre_malformed), 0, P.n, s));
+    clear_params Z{};
+    Z.p[0] = P.tally; Z.bytes[0] = P.tally ? 4 * sizeof(unsigned long long) : 0;
+    Z.p[1] = const_cast<uint8_t*>(P.pre_malformed); Z.bytes[1] = P.pre_malformed ? P.n : 0;
     J.small = small_path_applies(P);
+    if (!J.small) {
+        if (int rc = ensure_pending(P.n)) return rc;
+        P.pending_count = reinterpret_cast<unsigned long long*>(sl->pending);
+        P.pending = sl->pending + 2;
+        Z.p[2] = sl->pending; Z.bytes[2] = sizeof(uint64_t);
+    }
+    if (Z.bytes[0] || Z.bytes[1] || Z.bytes[2]) {
+        const uint64_t units = Z.bytes[1] / 16 / BLOCK + 1;
+        hipLaunchKernelGGL(clear_kernel, dim3((unsigned)(units < 256 ? units : 256)), dim3(BLOCK), 0, s, Z);
+        HIP_TRY(hipGetLastError());
+    }
     if (J.small) { ++g->stats[JJS_PATH_LATENCY]; return JJS_OK; }
-    if (int rc = ensure_pending(P.n)) return rc;
-    P.pending_count = reinterpret_cast<unsigned long long*>(sl->pending);
-    P.pending = sl->pending + 2;
-    HIP_TRY(hipMemsetAsync(sl->pending, 0, sizeof(uint64_t), s));
     J.try_keys = key_path_applies(P);
     if (!J.try_keys) { ++g->stats[JJS_PATH_THROUGHPUT]; return JJS_OK; }
     // The keys are counted (and, for a wire call, decoded once each) on the slot's key stream, with the clearing of
