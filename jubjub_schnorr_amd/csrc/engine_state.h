@@ -105,7 +105,8 @@ struct call_slot {
     uint64_t seen_n = 0;              // ... whose batch had this many items in
     uint32_t seen_cols = 0;           // ... this many key columns
     hipStream_t key_stream = nullptr; // the per-key kernels of the slot's call run here, beside the challenge hashes
-    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr, key_ahead = nullptr;
+    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr, key_ahead = nullptr, key_chains = nullptr;
+    hipStream_t table_stream = nullptr;   // key_table_kernel runs here, at the lowest priority: see job_keys
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
     hipStream_t last_stream = nullptr;// ... and the stream it was issued on
 };
@@ -157,6 +158,7 @@ struct device_state {
     size_t msig_items = 0, msig_transcripts = 0;
     int grid_msig = 0;
     int key_priority = 0;                // stream priority of the slots' key streams
+    int table_priority = 0;              // ... and of their table streams (the lowest)
     uint64_t stats[JJS_PATH_STATS] = {}; // jjs_path_stats: which path the calls on this device took
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     hipEvent_t side_join = nullptr, ingest_done = nullptr;

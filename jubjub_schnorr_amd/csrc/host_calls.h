@@ -306,6 +306,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     // the arena and the counters may still be in use by the previous call's last launches
     HIP_TRY(hipStreamWaitEvent(g->copy_stream, g->last_use, 0));
     HIP_TRY(hipStreamWaitEvent(g->stream, g->last_use, 0));
+    J.host_fed = true;
     if (int rc = job_begin(J, g->stream)) return rc;
     // The ranges of the block are queued on several streams in turn: a launch waits for every block of its predecessor on
     // the same stream, and a block of hashes lives for 1.4 ms, so on one stream the chip runs half empty at the end of

@@ -87,6 +87,7 @@ int init_device(device_state& d, int ordinal) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         d.key_priority = hi;
+        d.table_priority = lo;
     }
     HIP_TRY(hipEventCreateWithFlags(&d.side_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ingest_done, hipEventDisableTiming));
@@ -133,6 +134,7 @@ int init_device(device_state& d, int ordinal) {
             HIP_TRY(hipEventCreateWithFlags(&c.key_mid, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_join, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_ahead, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_chains, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.seen), sizeof(key_feedback), hipHostMallocDefault));
             memset(c.seen, 0, sizeof(key_feedback));
         }
@@ -147,6 +149,8 @@ int init_device(device_state& d, int ordinal) {
         for (int i : order) HIP_TRY(hipStreamCreateWithPriority(&d.slots[i].key_stream, hipStreamNonBlocking, d.key_priority));
     }
     for (hipStream_t& is : d.ingest) HIP_TRY(hipStreamCreateWithPriority(&is, hipStreamNonBlocking, d.key_priority));
+    for (call_slot& c : d.slots)
+        if (c.key_stream) HIP_TRY(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, d.table_priority));
     HIP_TRY(hipMalloc(&d.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d.comb_gn, COMB_TABLE_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d.tag, 32));
@@ -175,11 +179,12 @@ void free_device(device_state& d) {
         if (b) (void)hipFree(b);
     for (call_slot& c : d.slots) {
         if (c.key_stream) { (void)hipStreamSynchronize(c.key_stream); (void)hipStreamDestroy(c.key_stream); }
+        if (c.table_stream) { (void)hipStreamSynchronize(c.table_stream); (void)hipStreamDestroy(c.table_stream); }
         void* sb[] = {c.workspace, c.pending, c.prep, c.wire, c.small, c.keys, c.key_pool};
         for (void* b : sb)
             if (b) (void)hipFree(b);
         if (c.seen) (void)hipHostFree(c.seen);
-        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join, c.key_ahead};
+        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join, c.key_ahead, c.key_chains};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }

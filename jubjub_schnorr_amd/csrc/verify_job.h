@@ -233,6 +233,7 @@ struct verify_job {
     hipStream_t s = nullptr;          // the caller's stream: begin and finish are queued on it
     hipStream_t side[HOST_SIDE_STREAMS] = {};   // further streams ranges were queued on (host-buffer calls), joined by finish
     bool small = false, try_keys = false, split = false, forked = false, keys_queued = false, open = false;
+    bool host_fed = false;            // a host-buffer call: the hashes are queued range by range as the uploads arrive
 };
 
 int launch_normalize(normalize_params N, uint64_t first, uint64_t count, uint64_t n_call, hipStream_t s) {
@@ -335,6 +336,7 @@ int job_ingest(verify_job& J, uint64_t first, uint64_t count, uint32_t cols, hip
 }
 
 constexpr uint64_t KEYS_AHEAD_MAX_ITEMS = 1u << 18;      // see launch_staged
+constexpr uint64_t TABLES_BEHIND_MIN_ITEMS = 3u << 18;   // see job_keys
 // Every key column of the call is in place (on the key stream's timeline: the caller has made it wait for whatever
 // put them there): count the distinct keys, decide on the device, build the per-key tables.
 int job_keys(verify_job& J) {
@@ -372,10 +374,30 @@ int job_keys(verify_job& J) {
     hipLaunchKernelGGL(key_scatter_kernel, dim3(item_blocks), dim3(BLOCK), 0, ks, K);
     HIP_TRY(hipEventRecord(sl->key_ahead, ks));                // the keys are counted and grouped: see launch_staged
     hipLaunchKernelGGL(key_chain_kernel, dim3(((K.quad_chains ? 5 : 1) * K.n_cols * K.max_keys + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ks, K);
+    // The tables are throughput work (2 700 waves of 50 k instructions for 4 096 keys).  In a batch whose hashes outlast the
+    // key kernels nothing needs them before the hashes have ended: on a stream of the LOWEST priority their blocks are
+    // dispatched when prepare_kernel has no block left to dispatch, into the wave slots its last blocks leave idle.  On the key
+    // stream (high priority, for the sake of the chains) they displaced hash waves in the middle of the batch: 2^20 items 9.67 ->
+    // 9.07 ms single, 16.95 -> 15.85 double, 11.96 -> 11.25 var-gen.  A smaller batch waits for its tables, and they stay on
+    // the key stream (2^18 items: 2.95 ms there, 3.43 behind the hashes; 2^19: 5.93 / 6.02; profiles/r03_table_stream_ab.txt).
+#if defined(JJS_AB_TABLES_ON_KEY_STREAM)     // build-time knobs of that A/B run
+    hipStream_t ts = ks;
+#elif defined(JJS_AB_TABLES_ON_TABLE_STREAM)
+    hipStream_t ts = sl->table_stream;
+#else
+    // (a host-buffer call of single signatures is still uploading when its key kernels start, and its hashes end with its
+    // tables: those stay on the key stream, 10.3-10.8 against 10.7-10.9 ms; double and var-gen calls, whose hashes last longer,
+    // gain 0.4-0.8 ms behind them)
+    hipStream_t ts = P.n >= TABLES_BEHIND_MIN_ITEMS && !(J.host_fed && K.n_cols == 1) ? sl->table_stream : ks;
+#endif
+    if (ts != ks) {
+        HIP_TRY(hipEventRecord(sl->key_chains, ks));
+        HIP_TRY(hipStreamWaitEvent(ts, sl->key_chains, 0));
+    }
     hipLaunchKernelGGL(key_table_kernel, dim3((unsigned)(((uint64_t)K.n_cols * K.max_keys * KT_MAX_POSITIONS + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, ks, K);
+                       dim3(BLOCK), 0, ts, K);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(sl->key_join, ks));
+    HIP_TRY(hipEventRecord(sl->key_join, ts));
     J.keys_queued = true;
     return JJS_OK;
 }
@@ -438,7 +460,11 @@ int job_finish(verify_job& J) {
 void job_abandon(verify_job& J) {
     if (!J.open) return;
     (void)hipGetLastError();
-    if (J.forked && hipEventRecord(sl->key_join, sl->key_stream) == hipSuccess) (void)hipStreamWaitEvent(J.s, sl->key_join, 0);
+    if (J.forked) {        // the key stream, and the table stream behind it
+        if (hipEventRecord(sl->key_chains, sl->key_stream) == hipSuccess && hipStreamWaitEvent(sl->table_stream, sl->key_chains, 0) == hipSuccess &&
+            hipEventRecord(sl->key_join, sl->table_stream) == hipSuccess)
+            (void)hipStreamWaitEvent(J.s, sl->key_join, 0);
+    }
     for (hipStream_t side : J.side)
         if (side && hipEventRecord(g->side_join, side) == hipSuccess) (void)hipStreamWaitEvent(J.s, g->side_join, 0);
     (void)hipEventRecord(sl->last_use, J.s);
