@@ -335,7 +335,10 @@ int job_ingest(verify_job& J, uint64_t first, uint64_t count, uint32_t cols, hip
     return JJS_OK;
 }
 
-constexpr uint64_t KEYS_AHEAD_MAX_ITEMS = 1u << 18;      // see launch_staged
+#ifndef JJS_KEYS_AHEAD_MIN_ITEMS
+#define JJS_KEYS_AHEAD_MIN_ITEMS (3u << 16)
+#endif
+constexpr uint64_t KEYS_AHEAD_MIN_ITEMS = JJS_KEYS_AHEAD_MIN_ITEMS, KEYS_AHEAD_MAX_ITEMS = 1u << 18;      // see launch_staged
 constexpr uint64_t TABLES_BEHIND_MIN_ITEMS = 3u << 18;   // see job_keys
 // Every key column of the call is in place (on the key stream's timeline: the caller has made it wait for whatever
 // put them there): count the distinct keys, decide on the device, build the per-key tables.
@@ -483,18 +486,19 @@ int launch_staged(const staged_call& C, hipStream_t s) {
                  ? JJS_OK : fail(JJS_ERR_HIP, "event between the caller's stream and the key stream");
     }
     if (!rc) rc = job_keys(J);
-    // A batch of up to 2^18 items -- one generation of prepare_kernel's blocks -- hashes only once its keys are counted and
-    // grouped (0.13-0.22 ms on the empty chip), so that the per-key chains (252 dependent doublings: 1.05 ms whatever the
-    // batch) start with the hashes.  Launched beside them, the key kernels waited for the first wave slot to come free (the
-    // blocks of prepare_kernel hold theirs for 1.5 ms) and the tables were ready 1.0 ms after the hashes: 2^18 items 3.55 ->
-    // 3.05 ms single, 5.6 -> 4.9 double, 4.5 -> 3.85 var-gen; 2^17: 2.84 -> 2.79, 4.0 -> 3.82, 3.44 -> 3.27
-    // (profiles/r03_keys_ahead_ab.txt, r03_timeline_medium.txt).  At 2^19 items the hashes outlast the key kernels
-    // either way and double batches lose 0.4 ms by waiting: larger batches start at once.  A batch whose keys turn out not to
-    // repeat has waited for nothing (0.25 ms at 2^18): the slot remembers how its last attempt that has ended came out, and
-    // after one that built no tables the hashes start at once (a caller who queues batch after batch without waiting for
-    // any gives the slot nothing to remember).
+    // A batch that fills every wave slot with its hashes but does not outlast its key kernels -- more than 3 * 2^16 items, up
+    // to 2^18: one generation of prepare_kernel's blocks -- hashes only once its keys are counted and grouped (0.13-0.22 ms on
+    // the empty chip), so that the per-key chains start with the hashes.  Launched beside them, the key kernels waited for the
+    // first wave slot to come free (the blocks of prepare_kernel hold theirs for 1.5 ms) and the tables were ready 1.0 ms after
+    // the hashes: 2^18 items 3.55 -> 3.05 ms single, 5.6 -> 4.9 double, 4.5 -> 3.85 var-gen (profiles/r03_keys_ahead_ab.txt,
+    // r03_timeline_medium.txt).  A smaller batch leaves wave slots free and its key kernels find them at once: waiting costs it
+    // 0.1 ms (2^16 items 1.73 -> 1.61 ms, 2^17 2.33 -> 2.22 without).  At 2^19 items the hashes outlast the key kernels either
+    // way and double batches lose 0.4 ms by waiting: larger batches start at once.  A batch whose keys turn out not to repeat
+    // has waited for nothing (0.25 ms at 2^18): the slot remembers how its last attempt that has ended came out, and after one
+    // that built no tables the hashes start at once (a caller who queues batch after batch without waiting for any gives the
+    // slot nothing to remember).
 #if !defined(JJS_AB_NO_KEYS_AHEAD)        // build-time knob of the A/B run recorded in DESIGN.md 6
-    if (!rc && J.try_keys && J.keys_queued && C.P.n <= KEYS_AHEAD_MAX_ITEMS && sl->keys_repeated)
+    if (!rc && J.try_keys && J.keys_queued && C.P.n > KEYS_AHEAD_MIN_ITEMS && C.P.n <= KEYS_AHEAD_MAX_ITEMS && sl->keys_repeated)
         rc = hipStreamWaitEvent(s, sl->key_ahead, 0) == hipSuccess ? JJS_OK : fail(JJS_ERR_HIP, "event between the key stream and the caller's stream");
 #endif
     if (!rc) rc = job_hash(J, 0, C.P.n, s);
