@@ -611,6 +611,21 @@ def test_key_table_path_wire_against_oracle(eng, scheme):
     assert (host(st2) == want[sel]).all()
 
 
+@pytest.mark.parametrize("n", [(1 << 15) - 1, 1 << 15, 3 << 16, (3 << 16) + 1, 1 << 18, (1 << 18) + 1, (3 << 18) - 1, 3 << 18])
+def test_key_kernel_scheduling_boundaries(eng, n):
+    """Either side of the sizes at which a resident call orders its key kernels differently (csrc/verify_job.h: the key
+    tables from 32 768 double signatures on, the keys counted ahead of the hashes above 3 * 2^16 and up to 2^18 items, the
+    tables behind the hashes from 3 * 2^18): the bench mix under 4 096 keys, statuses known by construction."""
+    import torch
+    import bench
+    for scheme in ("single", "double", "vargen"):
+        arrays, expect = bench.make_inputs(eng, scheme, n, 0)
+        for _ in range(2):                       # the second call finds the slot's memory of the first
+            st, tally = eng.verify(scheme, *[arrays[k] for k in ARG_ORDER[scheme]])
+            assert torch.equal(st, expect), (scheme, n)
+            assert host(tally).tolist() == [int((expect == k).sum()) for k in range(4)]
+
+
 @pytest.mark.parametrize("n_keys", [1, 2, 1024, 1025, 8191, 8192, 8193, 1 << 17])
 def test_key_table_decision_boundary(eng, n_keys):
     """2^17 + 5 single signatures under 1 ... 2^17 keys: either side of the engine's on-device decisions (at most
