@@ -7,10 +7,14 @@
 One "step" = one pass of the verify hot path over one batch of synthetic signatures that is
 already resident in HBM.  The headline (`value`) is BASELINE.json configs[1]: 2^20 single signatures on
 one MI355X; the same invocation then times configs[2] (2^20 double) and configs[4] (2^20 var-generator)
-with the same protocol and reports them under `schemes`.  For N > 1 the driver launches one process per
-GPU (torch.distributed.run); every rank verifies its own shard -- 2^20 items per GPU at N = 2, 4 and
-2^21 per GPU at N = 8, which is configs[3] (2^24 single signatures over 8 GPUs) exactly -- and the only
-exchange is an RCCL all-reduce of the 4-counter tally, inside the timed region.  Rank 0 prints ONE JSON line.
+with the same protocol and reports them under `schemes`.  For N > 1 there is one process per GPU: started by
+the driver (torch.distributed.run), or -- `python3 bench.py --gpus N` with WORLD_SIZE unset -- by bench.py itself as
+a child process, before it has made any GPU call.  Every rank verifies its own shard -- 2^20 items per GPU at
+N = 2, 4 and 2^21 per GPU at N = 8, which is configs[3] (2^24 single signatures over 8 GPUs) exactly; the N = 1
+run also times 2^21 (`single_2p21`), the same-size base of that point -- and the only exchange is an RCCL
+all-reduce of the 4-counter tally, inside the timed region.  `config.distributed` lists every rank's device
+(ordinal, PCI bus id, uuid) and checks the all-reduced tally against the sum of the ranks' known tallies.
+Rank 0 prints ONE compact JSON line; the whole record goes to gpurun_out/bench_full_n<N>.json.
 
 Synthetic inputs: seed 0x6a6a73, 4096 distinct keys, item i signed with key i mod
 4096 by the library's own GPU signer (tests pin it bit-exact to the oracle), then 15/16 valid,
@@ -437,10 +441,14 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     # bit-exact check against the by-construction expectation (every rank)
     ok_status = bool(torch.equal(st, expect))
     ok_tally = bool(torch.equal(tally_local.cpu(), want_tally.cpu()))
-    total_expected = want_tally.clone().cuda()
+    # the all-reduced tally against the sum of the N per-rank tallies, which are known by construction and gathered as
+    # python objects (not through the collective that is being checked)
+    rank_tallies = [want_tally.cpu().tolist()]
     if dist is not None:
-        dist.all_reduce(total_expected)
-    ok_global = bool(torch.equal(tally.cpu(), total_expected.cpu()))
+        rank_tallies = [None] * world
+        dist.all_gather_object(rank_tallies, want_tally.cpu().tolist())
+    summed = [sum(t[k] for t in rank_tallies) for k in range(4)]
+    ok_global = tally.cpu().tolist() == summed
     ok = ok_status and ok_tally and ok_global
     if rank != 0:
         return None, ok
@@ -462,6 +470,8 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
         "items_per_gpu": n,
         "distinct_keys_per_gpu": min(n_keys, n),
         "bit_exact": {"status_vs_construction": ok_status, "tally_local": ok_tally, "tally_global": ok_global},
+        "tally_allreduce": {"rank_tallies": rank_tallies, "sum_of_rank_tallies": summed, "allreduced": tally.cpu().tolist(),
+                            "equal": ok_global, "ranks": len(rank_tallies)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes * n,
@@ -503,6 +513,145 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     return rec, ok
 
 
+def write_full_record(full: dict):
+    """The whole record (every scheme's roofline, clocks, notes, per-call times) goes to a file; stdout carries the compact
+    line, which fits the tail a driver keeps."""
+    for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_full_n%d.json" % full["n_gpus"])
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
+
+
+def _round(x, digits=4):
+    return round(x, digits) if isinstance(x, float) else x
+
+
+def compact_line(full: dict, path) -> dict:
+    """The ONE line of stdout: the contract's keys, `roofline` with the binding (valu-issue) figures and the host-buffer
+    rates of the headline scheme inside it, `cpu_baseline`, and one short record per secondary measurement."""
+    def binding(alu):
+        if not alu:
+            return None
+        return {"bound": alu["bound"], "frac": _round(alu["frac"]), "sclk_ghz": _round(alu["sclk_ghz"]), "sclk_sampled": alu["sclk_sampled"],
+                "achieved": _round(alu["achieved"], 0), "peak": _round(alu["peak"], 0), "unit": alu["unit"],
+                "cycles_per_wave_instr": _round(alu["cycles_per_wave_instr"]), "floor_cycles_per_wave_instr": _round(alu["floor_cycles_per_wave_instr"]),
+                "valu_wave_instr_per_64_verifies": _round(alu["valu_wave_instr_per_64_verifies"], 0),
+                "per_kernel": alu.get("per_kernel"), "source": alu.get("source")}
+
+    def host_rates(hb):
+        if not hb:
+            return None
+        return {f: _round(hb[f]["value"], 0) for f in ("affine", "ext", "wire") if f in hb}
+
+    def short(rec):
+        if rec is None:
+            return None
+        r = rec["roofline"] if "roofline" in rec else {}
+        out = {"value": _round(rec["value"], 0), "ms_per_step": _round(rec["ms_per_step"]), "bit_exact": all(rec["bit_exact"].values())}
+        if r:
+            out["hbm_frac"] = _round(r["frac"], 5)
+            out["traffic"] = r.get("traffic")
+        b = binding(rec.get("alu_roofline"))
+        if b:
+            out["binding_frac"] = b["frac"]; out["sclk_ghz"] = b["sclk_ghz"]
+        if rec.get("host_buffer"):
+            out["host_buffer"] = host_rates(rec["host_buffer"])
+        if rec.get("cpu_baseline"):
+            out["cpu_baseline"] = {"value": _round(rec["cpu_baseline"]["value"], 0), "cores": rec["cpu_baseline"]["cores"],
+                                   "statuses_equal_gpu": rec["cpu_baseline"]["statuses_equal_gpu"]}
+        return out
+
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    cfg = dict(full["config"])
+    d = cfg["distributed"]
+    cfg["distributed"] = {"backend": d["backend"], "world_size": d["world_size"], "ranks": d["ranks"], "distinct_devices": d["distinct_devices"],
+                          "rehearsal_ranks_share_devices": d["rehearsal_ranks_share_devices"],
+                          "devices": [{"rank": i["rank"], "device": i["device"], "pci_bus_id": i["pci_bus_id"], "uuid": i["uuid"]} for i in d["devices"]],
+                          "tally_allreduce": {k: d["tally_allreduce"][k] for k in ("sum_of_rank_tallies", "allreduced", "equal", "ranks")}}
+    line["config"] = cfg
+    line["bit_exact"] = full["bit_exact"]
+    r = dict(full["roofline"])
+    r.pop("note", None)
+    b = binding(full.get("alu_roofline"))
+    hb = host_rates(full.get("host_buffer"))
+    # flat copies first (a record that keeps scalars only still shows them), then the objects
+    if b:
+        r.update({"binding_bound": b["bound"], "binding_frac": b["frac"], "binding_sclk_ghz": b["sclk_ghz"], "binding_source": b["source"]})
+    if hb:
+        r.update({"host_buffer_%s_per_s" % f: v for f, v in hb.items()})
+    r["binding"] = b
+    r["host_buffer"] = hb
+    line["roofline"] = r
+    if "cpu_baseline" in full:
+        c = dict(full["cpu_baseline"])
+        c.pop("thread_probe", None)
+        line["cpu_baseline"] = c
+    if "pipelined_two_streams" in full:
+        line["pipelined_two_streams"] = _round(full["pipelined_two_streams"]["value"], 0)
+    if "schemes" in full:
+        line["schemes"] = {k: short(v) for k, v in full["schemes"].items()}
+    if "unique_keys" in full:
+        line["unique_keys"] = short(full["unique_keys"])
+    if "single_2p21" in full:
+        line["single_2p21"] = short(full["single_2p21"])
+    for k in ("small_host_calls", "multisig"):
+        if k in full:
+            line[k] = full[k]
+    line["full_record"] = path
+    return line
+
+
+def launch_ranks(n: int, argv: list) -> int:
+    """`bench.py --gpus N` without a launcher: one rank per GPU under torch.distributed.run, as a child process (this
+    process has not touched the GPU).  Rank 0's JSON line is relayed on stdout, everything else on stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = []
+    for line in p.stdout:
+        if line.startswith("{"):
+            lines.append(line)
+        else:
+            sys.stderr.write(line)
+    rc = p.wait()
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended without a result line\n")
+        rc = 1
+    return rc
+
+
+def device_identity(rank: int, local_rank: int, device_index: int) -> dict:
+    """What tells one GPU of a node from another: ordinal, PCI bus id, uuid (all_gather_object'ed into config.distributed)."""
+    import socket
+    import torch
+    prop = torch.cuda.get_device_properties(device_index)
+    bus = None
+    if all(hasattr(prop, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = "%04x:%02x:%02x.0" % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+    uuid = getattr(prop, "uuid", None)
+    return {"rank": rank, "local_rank": local_rank, "device": device_index, "pci_bus_id": bus, "uuid": str(uuid) if uuid is not None else None,
+            "name": prop.name, "host": socket.gethostname(), "pid": os.getpid(),
+            "visible_devices": torch.cuda.device_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -531,12 +680,18 @@ def main():
     ap.add_argument("--lib", default=None, help="another in-tree build of the engine (A/B timing of kernel variants)")
     args = ap.parse_args()
 
+    # N > 1 from a plain command line (`python3 bench.py --gpus 8`): this process has made no GPU call yet (torch is not even
+    # imported), so it starts the ranks as a CHILD process, relays rank 0's one JSON line and leaves with the child's code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run, one rank per GPU")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: unset WORLD_SIZE (bench.py then starts its own ranks) "
+                         f"or launch with torch.distributed.run --nproc-per-node {args.gpus}")
     rehearsal = args.backend != "nccl"
     device_index = local_rank % max(1, torch.cuda.device_count()) if rehearsal else local_rank
     torch.cuda.set_device(device_index)       # before any other GPU call of this process
@@ -551,6 +706,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         backend = dist.get_backend()
         assert dist.get_world_size() == args.gpus and backend == args.backend, (dist.get_world_size(), backend)
+    identity = device_identity(rank, local_rank, device_index)
+    identities = [identity]
+    if dist is not None:
+        identities = [None] * world
+        dist.all_gather_object(identities, identity)
 
     if args.lib:
         from jubjub_schnorr_amd import _ffi
@@ -566,7 +726,9 @@ def main():
         records[scheme] = rec
         all_ok = all_ok and ok
         torch.cuda.empty_cache()
+    extras = {}
     unique = None
+    base_2p21 = None
     if args.scheme == "all" and not (args.wire or args.ext):
         # the same size with every signature under its own key: no key repeats, so the engine's key tables cannot
         # engage and every public key is a fresh variable point (the worst case for the path; round 1's number)
@@ -574,10 +736,23 @@ def main():
         unique, ok = run_scheme(eng, "single", n, args, dist, rank, world, False, n_keys=n)
         all_ok = all_ok and ok
         torch.cuda.empty_cache()
+        if world == 1 and args.log2_items_per_gpu is None:
+            # the shard size of BASELINE.json configs[3] (2^24 over 8 GPUs = 2^21 per GPU) on ONE GPU: the same-size base of the
+            # N = 8 point of a scaling run (N = 1, 2, 4 run 2^20 per GPU).  A secondary record, never `value`.
+            lean = argparse.Namespace(**{**vars(args), "no_two_streams": True, "no_host_buffers": True, "no_clock_sampling": True})
+            base_2p21, ok = run_scheme(eng, "single", 1 << 21, lean, dist, rank, world, False)
+            all_ok = all_ok and ok
+            torch.cuda.empty_cache()
 
     if rank == 0:
         head = records[schemes[0]]
-        out = {
+        devices = sorted({(i["host"], i["pci_bus_id"] or i["uuid"] or i["device"]) for i in identities})
+        distributed = {"backend": backend, "world_size": world, "ranks": len(identities), "distinct_devices": len(devices),
+                       "rehearsal_ranks_share_devices": bool(rehearsal and world > 1),
+                       "devices": [{k: i[k] for k in ("rank", "local_rank", "device", "pci_bus_id", "uuid", "name", "host", "pid",
+                                                      "visible_devices")} for i in identities],
+                       "tally_allreduce": head["tally_allreduce"]}
+        full = {
             "metric": "Schnorr verifications/sec",
             "value": head["value"],
             "unit": "verifications/s",
@@ -594,30 +769,34 @@ def main():
                        "global_items": head["items_per_gpu"] * world,
                        "input_format": "wire (compressed points)" if args.wire else "extended (U, V, Z)" if args.ext else "affine",
                        "parallelism": f"batch-sharded x{world}, RCCL tally all-reduce",
-                       "distributed": {"backend": backend, "world_size": world,
-                                       "rehearsal_ranks_share_devices": bool(rehearsal and world > 1)},
+                       # flat copies of what config.distributed proves (a record that keeps scalars only still shows them)
+                       "backend": backend, "world_size": world, "ranks": len(identities), "distinct_devices": len(devices),
+                       "device_bus_ids": ",".join(str(i["pci_bus_id"] or i["uuid"] or i["device"]) for i in identities),
+                       "allreduced_tally_equals_sum_of_rank_tallies": head["tally_allreduce"]["equal"],
+                       "distributed": distributed,
                        "distinct_keys_per_gpu": head["distinct_keys_per_gpu"],
-                       "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points; keys as SURVEY.md 8(d): "
-                              "4 096 key pairs, item i signed by key i mod 4 096"},
+                       "mix": "15/16 valid, 1/32 wrong key, 1/64 tampered m, 1/64 invalid points; 4 096 key pairs (SURVEY.md 8d)"},
             "bit_exact": head["bit_exact"],
             "roofline": head["roofline"],
             "alu_roofline": head["alu_roofline"],
             "clocks": head.get("clocks"),
         }
-        if "cpu_baseline" in head:
-            out["cpu_baseline"] = head["cpu_baseline"]
-        if "pipelined_two_streams" in head:
-            out["pipelined_two_streams"] = head["pipelined_two_streams"]
-        if "host_buffer" in head:
-            out["host_buffer"] = head["host_buffer"]
+        for k in ("cpu_baseline", "pipelined_two_streams", "host_buffer"):
+            if k in head:
+                full[k] = head[k]
         if len(schemes) > 1:        # BASELINE.json metric: "single + double" (and configs[4], the per-item generator)
-            out["schemes"] = {s: records[s] for s in schemes[1:]}
+            full["schemes"] = {s: records[s] for s in schemes[1:]}
         if unique is not None:
-            out["unique_keys"] = {k: unique[k] for k in ("value", "unit", "ms_per_step", "workload", "distinct_keys_per_gpu",
-                                                          "bit_exact", "roofline", "alu_roofline", "clocks")}
-            out["unique_keys"]["note"] = ("single scheme, every signature under its own public key: the key-table path cannot "
-                                          "engage; `value` above is the SURVEY.md 8(d) workload, whose 4 096 keys repeat")
-        print(json.dumps(out), flush=True)
+            full["unique_keys"] = {k: unique[k] for k in ("value", "unit", "ms_per_step", "workload", "distinct_keys_per_gpu",
+                                                           "bit_exact", "roofline", "alu_roofline", "clocks")}
+            full["unique_keys"]["note"] = ("single scheme, every signature under its own public key: the key-table path cannot "
+                                           "engage; `value` above is the SURVEY.md 8(d) workload, whose 4 096 keys repeat")
+        if base_2p21 is not None:
+            full["single_2p21"] = {k: base_2p21[k] for k in ("value", "unit", "ms_per_step", "workload", "items_per_gpu", "bit_exact")}
+        for k, v in extras.items():
+            full[k] = v
+        path = write_full_record(full)
+        print(json.dumps(compact_line(full, path)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
