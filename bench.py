@@ -744,6 +744,14 @@ def main():
             all_ok = all_ok and ok
             torch.cuda.empty_cache()
 
+    if rank == 0 and world == 1 and args.scheme == "all" and not (args.wire or args.ext or args.no_host_buffers):
+        # the reference's own call pattern: few signatures per blocking call, several host threads (secondary record)
+        from jubjub_schnorr_amd.tools import small_host_calls
+        try:
+            extras["small_host_calls"] = small_host_calls.measure(eng, sys.modules[__name__])
+            all_ok = all_ok and extras["small_host_calls"]["bit_exact"]
+        except Exception as e:          # a box without gcc: the record says so, the bench goes on
+            extras["small_host_calls"] = {"error": str(e)[:300]}
     if rank == 0:
         head = records[schemes[0]]
         devices = sorted({(i["host"], i["pci_bus_id"] or i["uuid"] or i["device"]) for i in identities})

@@ -41,8 +41,11 @@
  * include/jjs_gpu_profiling.h) that the product never loads.
  *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
- * thread and are serialised by one internal mutex (jjs_stream_sync only reads state under it and waits
- * outside).  The *_dev calls are asynchronous.  A call takes one of the engine's call slots by size (three for calls of
+ * thread.  One internal mutex guards the engine's state; it is held while a call is QUEUED, never while a call waits:
+ * the *_dev calls are asynchronous, jjs_stream_sync waits outside it, and a blocking host-buffer call of at most
+ * 131 072 items holds it only to take a staging lane (eight per device) and to queue its copies and launches, so that
+ * such calls from several host threads run side by side on the device.  Larger host-buffer calls (each fills the device
+ * by itself) run one at a time and hold the mutex for their duration.  A call takes one of the engine's call slots by size (three for calls of
  * at most 16 384 items, three for at most 131 072, two for larger ones): calls in different slots share no buffer and
  * overlap on the device when they are issued on different streams; calls in one slot are ordered on the device (each
  * waits for the previous one, also across streams).
@@ -135,8 +138,36 @@ int jjs_stream_sync(void* stream);
 #define JJS_PATH_KEYS_POOL_TOO_SMALL 6
 #define JJS_PATH_KEYS_NO_MEMORY 7
 #define JJS_PATH_KEY_POOL_BYTES 8
-#define JJS_PATH_STATS 9
+/* blocking host-buffer calls of at most 131 072 items: launches on the staging lanes, and calls they served (calls of at
+ * most 4 096 items of one scheme and format that arrive while such a launch runs share the next one) */
+#define JJS_PATH_LANE_LAUNCHES 9
+#define JJS_PATH_LANE_CALLS 10
+#define JJS_PATH_STATS 11
 int jjs_path_stats(uint64_t out[JJS_PATH_STATS]);
+
+/* ---- pre-sizing, trimming -----------------------------------------------------------------------------------
+ * The engine's buffers are grow-only and allocated on first use: the first call of a larger size than any before it
+ * allocates (never waits for the device: a replaced buffer is kept until jjs_trim / jjs_shutdown), which costs that call
+ * the allocation time.  A service that knows its call shapes pre-sizes at start-up:
+ *   jjs_reserve(scheme, format, n_items, host_buffers) allocates what a verification call of that scheme (JJS_SCHEME_*),
+ *   input format (JJS_FORMAT_*) and at most n_items items needs, in every call slot such a call can land in; with
+ *   host_buffers != 0 also the staging of the blocking host-buffer entry point of that shape (for every driven device).
+ * jjs_trim() waits for the devices to go idle and frees the retired buffers and the key-table pools (which come back,
+ * at the size they had, with the next call that takes the key tables).  jjs_memory_stats: bytes held, by kind. */
+#define JJS_SCHEME_SINGLE 0
+#define JJS_SCHEME_DOUBLE 1
+#define JJS_SCHEME_VARGEN 2
+#define JJS_FORMAT_AFFINE 0
+#define JJS_FORMAT_EXT 1
+#define JJS_FORMAT_WIRE 2
+int jjs_reserve(int scheme, int format, size_t n_items, int host_buffers);
+int jjs_trim(void);
+#define JJS_MEMORY_KEY_POOLS 0
+#define JJS_MEMORY_SLOT_BUFFERS 1
+#define JJS_MEMORY_HOST_STAGING 2
+#define JJS_MEMORY_RETIRED 3
+#define JJS_MEMORY_STATS 4
+int jjs_memory_stats(uint64_t out[JJS_MEMORY_STATS]);
 
 /* ---- wire formats (reference `to_bytes` / `from_bytes`), device buffers, asynchronous ------------------
  * Points travel compressed (32 bytes: little-endian v, parity of u in bit 255) and are decoded on the

@@ -32,6 +32,9 @@ SIGNATURES = {
     "jjs_verify_vargen_dev": [_P, _P, _P, _P, _P, _Z, _P, _P, _P],
     "jjs_stream_sync": [_P],
     "jjs_path_stats": [_P],
+    "jjs_reserve": [_I, _I, _Z, _I],
+    "jjs_trim": [],
+    "jjs_memory_stats": [_P],
     "jjs_verify_single_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_double_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],
     "jjs_verify_vargen_wire_dev": [_P, _P, _P, _Z, _P, _P, _P],

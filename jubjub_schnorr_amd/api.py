@@ -134,7 +134,7 @@ class Engine:
         return status, tally
 
     PATH_STAT_NAMES = ("latency", "throughput", "key_tables_wide", "key_tables_narrow", "keys_do_not_repeat",
-                       "keys_probe_limit", "keys_pool_too_small", "keys_no_memory", "key_pool_bytes")
+                       "keys_probe_limit", "keys_pool_too_small", "keys_no_memory", "key_pool_bytes", "lane_launches", "lane_calls")
 
     def path_stats(self) -> dict:
         """Which method the calls on the current device took so far (jjs_path_stats): calls per path, and the bytes the
@@ -142,6 +142,25 @@ class Engine:
         out = (ctypes.c_uint64 * len(self.PATH_STAT_NAMES))()
         _ffi.check(self._lib.jjs_path_stats(out), "jjs_path_stats")
         return dict(zip(self.PATH_STAT_NAMES, (int(v) for v in out)))
+
+    _SCHEME_IDS = {"single": 0, "double": 1, "vargen": 2}
+    _FORMAT_IDS = {"affine": 0, "ext": 1, "wire": 2}
+    MEMORY_STAT_NAMES = ("key_pools", "slot_buffers", "host_staging", "retired")
+
+    def reserve(self, scheme: str, n_items: int, fmt: str = "affine", host_buffers: bool = False) -> None:
+        """Pre-size the engine for calls of this scheme, input format ("affine", "ext", "wire") and at most `n_items` items
+        (jjs_reserve): no later call of that shape allocates.  `host_buffers`: also the staging of the numpy (blocking) calls."""
+        _ffi.check(self._lib.jjs_reserve(self._SCHEME_IDS[scheme], self._FORMAT_IDS[fmt], int(n_items), int(bool(host_buffers))),
+                   "jjs_reserve")
+
+    def trim(self) -> None:
+        """Wait for the device, free retired buffers and the key-table pools (jjs_trim)."""
+        _ffi.check(self._lib.jjs_trim(), "jjs_trim")
+
+    def memory_stats(self) -> dict:
+        out = (ctypes.c_uint64 * len(self.MEMORY_STAT_NAMES))()
+        _ffi.check(self._lib.jjs_memory_stats(out), "jjs_memory_stats")
+        return dict(zip(self.MEMORY_STAT_NAMES, (int(v) for v in out)))
 
     _WIRE_WIDTHS = {"single": (64, 32, 32), "double": (96, 64, 32), "vargen": (64, 64, 32)}
 

@@ -105,12 +105,15 @@ struct call_slot {
     uint64_t seen_n = 0;              // ... whose batch had this many items in
     uint32_t seen_cols = 0;           // ... this many key columns
     hipStream_t key_stream = nullptr; // the per-key kernels of the slot's call run here, beside the challenge hashes
-    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr, key_ahead = nullptr, key_chains = nullptr;
+    hipEvent_t key_fork = nullptr, key_mid = nullptr, key_join = nullptr, key_ahead = nullptr, key_chains = nullptr, key_cleared = nullptr;
     hipStream_t table_stream = nullptr;   // key_table_kernel runs here, at the lowest priority: see job_keys
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
     hipStream_t last_stream = nullptr;// ... and the stream it was issued on
 };
-constexpr int N_SMALL_SLOTS = 3;
+#ifndef JJS_SMALL_SLOTS
+#define JJS_SMALL_SLOTS 6
+#endif
+constexpr int N_SMALL_SLOTS = JJS_SMALL_SLOTS;   // six since round 4: host threads with a few signatures per call keep more than three in flight
 constexpr size_t SMALL_SLOT_ITEMS = 16384;
 // Calls of up to MEDIUM_SLOT_ITEMS items take one of N_MEDIUM_SLOTS medium slots in turn: such a call is a few waves
 // per SIMD at most and is bound by the latency of one signature (~1.7 ms), so calls on different streams overlap almost
@@ -131,6 +134,59 @@ constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
 constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
+
+// Host-buffer calls of at most LANE_MAX_ITEMS items do not go through the piece-by-piece pipeline of the large ones
+// (host_calls.h): each runs on a LANE -- a stream, a pinned host area and a device area -- and holds the engine's mutex only
+// while it joins the lane and while its kernels are queued (some tens of microseconds), not while it copies or waits.  So T
+// service threads that each verify a few signatures per call -- what the reference's callers do (one item per call,
+// src/keys/public.rs:114-118) -- overlap on the device like T streams do.
+// And they COMBINE: calls of at most COMBINE_MAX_CALL_ITEMS items of one scheme and input format that arrive while a lane
+// launch of that shape runs append their items to the lane that is filling, and that lane goes to the device as ONE launch
+// (of up to COMBINE_CAP_ITEMS items) when the launch ahead of it has ended -- a launch of 4 096 signatures returns as soon as
+// one of 1 024: the latency path has lanes to spare at these sizes, so eight threads are served in the time of one.  A call
+// that finds no launch of its shape running is launched at once, alone: one thread's latency is what it was.  Launches of
+// different shapes, and calls too large to combine, run side by side.  Every caller gets its own statuses and its own tally
+// (counted on the host from its statuses).
+struct host_lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;        // end of the launch in progress on the lane
+    uint8_t* dev = nullptr;           // device area: the columns of the launch, its statuses (grow-only)
+    size_t dev_bytes = 0;
+    uint8_t* pinned = nullptr;        // pinned host area, same layout (grow-only)
+    size_t pinned_bytes = 0;
+    // the launch that is being put together / runs on the lane
+    enum : int { FREE = 0, OPEN = 1, LAUNCHED = 2, DONE = 3 };
+    int state = FREE;
+    int scheme = -1, format = -1;     // call shape of the members
+    bool combinable = false;          // further calls may join while it is OPEN
+    bool combinable_shape = false;    // a launch of combinable calls (LAUNCHED: no second one of its shape beside it)
+    size_t cap = 0, items = 0;        // items the layout holds / items the members have claimed
+    unsigned copying = 0, members = 0;
+    std::chrono::steady_clock::time_point gather_until{};    // not launched before (see COMBINE_WINDOW_US)
+    int rc = 0;                       // outcome of the launch (JJS_OK or the error every member returns)
+    char err[256] = "";
+};
+constexpr int N_HOST_LANES = 8;
+#ifndef JJS_LANE_MAX_ITEMS
+#define JJS_LANE_MAX_ITEMS 131072
+#endif
+constexpr size_t LANE_MAX_ITEMS = JJS_LANE_MAX_ITEMS;
+#ifndef JJS_COMBINE_MAX_CALL_ITEMS
+#define JJS_COMBINE_MAX_CALL_ITEMS 4096
+#endif
+constexpr size_t COMBINE_MAX_CALL_ITEMS = JJS_COMBINE_MAX_CALL_ITEMS, COMBINE_CAP_ITEMS = 16384;      // the cap: what the latency path takes
+// When a launch ends, the lane that has been filling behind it is not launched before this many microseconds have passed:
+// the threads that launch served come back within microseconds of each other and find it still open.  (Launched at once, it
+// would leave without them, and the threads would take turns in half-empty launches.)  A caller that finds no launch of its
+// shape running does not wait.
+#ifndef JJS_COMBINE_WINDOW_US
+#define JJS_COMBINE_WINDOW_US 50
+#endif
+constexpr unsigned COMBINE_WINDOW_US = JJS_COMBINE_WINDOW_US;
+// A buffer that was replaced by a larger one.  It may still be in use by launches that are in flight, and hipFree would
+// wait for every stream of the device: it is kept until jjs_trim / jjs_shutdown (grow-only buffers grow geometrically, so
+// what is kept is less than what is live).
+struct retired_buffer { void* p; bool host; size_t bytes; };
 
 constexpr size_t HOST_MAX_PIECES = 64;      // pieces a host-buffer call uploads its block in (plan_pieces)
 #ifndef JJS_HOST_SIDE_STREAMS
@@ -168,6 +224,11 @@ struct device_state {
     uint8_t* pinned = nullptr;           // host-buffer calls: pinned host staging (two input slots + statuses, grow-only)
     size_t pinned_bytes = 0;
     hipEvent_t chunk_up[HOST_MAX_PIECES] = {}, chunk_done[HOST_MAX_PIECES] = {};   // per piece of a host-buffer call: uploaded, converted
+    host_lane lanes[N_HOST_LANES];       // small and medium host-buffer calls: one lane per launch in flight or filling
+    std::atomic<uint64_t> lane_epoch{0}; // bumped (under the engine's mutex) whenever a lane changes state: what waiting callers poll
+    size_t lane_last_items[3][3] = {};   // [scheme][format]: items of the last combined launch (sizes the next lane)
+    std::vector<retired_buffer> retired; // replaced buffers, freed by jjs_trim / jjs_shutdown
+    size_t retired_bytes = 0;
 };
 
 // RCCL is needed only when one process drives several devices, so it is loaded on demand.
@@ -185,6 +246,7 @@ constexpr int MAX_DEVICES = 16;
 
 struct library_state {
     std::mutex mu;
+    std::condition_variable lane_cv;       // a host lane has changed state (waited for under `mu`)
     std::vector<device_state*> devs;       // devices this process drives (jjs_init)
     bool virtual_devices = false;          // test mode: several logical devices on one physical device
     rccl_api rccl;
@@ -196,6 +258,7 @@ library_state L;
 // per-device worker of run_host for its own block (the workers run concurrently, one device each).
 thread_local device_state* g = nullptr;
 thread_local call_slot* sl = nullptr;      // slot of the call in progress on this thread (pick_slot)
+thread_local call_slot* forced_slot = nullptr;   // jjs_reserve: the slot the next builder sizes, instead of the one whose turn it is
 
 // One message buffer per host thread: jjs_last_error() describes the calling thread's last failure and a
 // pointer it returned is never written by another thread.
@@ -241,6 +304,7 @@ bool g_pin_hash_seed = false;     // set by jjs_debug_pin_hash_seed: the dedup h
 
 // Small calls take the small slots in turn, everything else the big one (see call_slot).
 void pick_slot(size_t n, hipStream_t s) {
+    if (forced_slot) { sl = forced_slot; return; }
     if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
     else if (n <= MEDIUM_SLOT_ITEMS) { sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium]; g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS; }
     else {
@@ -265,53 +329,98 @@ int end_shared(hipStream_t s) {
     return JJS_OK;
 }
 
+// Grow-only buffers: the replacement is allocated first, the old buffer is retired (launches in flight may still use it; it
+// is freed by jjs_trim / jjs_shutdown).  No call waits for the device here.
+size_t grown(size_t want) {              // the smallest of 2^k, 1.5 * 2^k that holds `want`: what is retired stays below what is live
+    size_t cap = 4096;
+    while (cap < want) cap <<= 1;
+    const size_t mid = cap / 4 * 3;
+    return mid >= want ? mid : cap;
+}
+void retire(void* p, bool host, size_t bytes) {
+    if (!p) return;
+    try {
+        g->retired.push_back(retired_buffer{p, host, bytes});
+        g->retired_bytes += bytes;
+    } catch (...) {                       // no room for the note: wait for the device and free it now
+        (void)hipDeviceSynchronize();
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+}
+void free_retired(device_state& d) {      // the caller has made sure that the device is idle
+    for (retired_buffer& r : d.retired) {
+        if (r.host) (void)hipHostFree(r.p); else (void)hipFree(r.p);
+    }
+    d.retired.clear();
+    d.retired_bytes = 0;
+}
+template <typename T>
+int regrow(T*& buf, size_t& have, size_t old_bytes, size_t want_units, size_t bytes) {
+    T* fresh = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fresh), bytes));
+    retire(buf, false, old_bytes);
+    buf = fresh;
+    have = want_units;
+    return JJS_OK;
+}
+
 int ensure_pending(size_t n) {
     if (n <= sl->pending_items) return JJS_OK;
-    if (sl->pending) {
-        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still use the old queue
-        HIP_TRY(hipFree(sl->pending));
-        sl->pending = nullptr; sl->pending_items = 0;
-    }
-    size_t cap = n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n;
-    HIP_TRY(hipMalloc(&sl->pending, (cap + 2) * sizeof(uint64_t)));
-    sl->pending_items = cap;
-    return JJS_OK;
+    const size_t cap = grown(n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n);
+    return regrow(sl->pending, sl->pending_items, (sl->pending_items + 2) * sizeof(uint64_t), cap, (cap + 2) * sizeof(uint64_t));
 }
 
 int ensure_prep(size_t n) {
     if (n <= sl->prep_items) return JJS_OK;
-    if (sl->prep) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(sl->prep));
-        sl->prep = nullptr; sl->prep_items = 0;
-    }
-    size_t cap = n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n;
-    HIP_TRY(hipMalloc(&sl->prep, cap * 65 + 64));
-    sl->prep_items = cap;
-    return JJS_OK;
+    const size_t cap = grown(n < SMALL_SLOT_ITEMS ? SMALL_SLOT_ITEMS : n);
+    return regrow(sl->prep, sl->prep_items, sl->prep_items * 65 + 64, cap, cap * 65 + 64);
 }
 
 int ensure_small(size_t bytes) {
     if (bytes <= sl->small_bytes) return JJS_OK;
-    if (sl->small) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(sl->small));
-        sl->small = nullptr; sl->small_bytes = 0;
-    }
-    HIP_TRY(hipMalloc(&sl->small, bytes));
-    sl->small_bytes = bytes;
-    return JJS_OK;
+    const size_t cap = grown(bytes);
+    return regrow(sl->small, sl->small_bytes, sl->small_bytes, cap, cap);
 }
 
 // Latency path (small_batch.h): two launches, every signature spread over 11 (single) or 21 (double) lanes.
-int launch_small(verify_params P, hipStream_t s) {
+// A call that is alone on the device spreads every signature over as many lanes as shorten its critical path: 8 pieces per
+// scalar and eight lanes per hash up to 4 096 items (small_batch.h).  That buys latency with work -- a call of 1 024 single
+// signatures is 416 waves instead of 180 -- and the device holds about one such call per 256 compute units at full speed: with
+// more in flight their waves share SIMDs and every call takes longer (four host threads of such calls: 1.9 x one thread's
+// rate).  So a small call that finds `others` small calls of other slots still running when it is queued takes the
+// economical cut (4 pieces, one lane per hash) from SMALL_ECONOMY_FROM others on.  Statuses do not depend on the cut.
+#ifndef JJS_SMALL_ECONOMY_FROM
+#define JJS_SMALL_ECONOMY_FROM 1
+#endif
+constexpr unsigned SMALL_ECONOMY_FROM = JJS_SMALL_ECONOMY_FROM;
+unsigned small_calls_in_flight() {
+    unsigned k = 0;
+    for (int i = 1; i <= N_SMALL_SLOTS; ++i) {
+        call_slot& c = g->slots[i];
+        if (&c != sl && hipEventQuery(c.last_use) == hipErrorNotReady) ++k;
+    }
+    (void)hipGetLastError();              // "not ready" is an answer, not a failure of this call
+    return k;
+}
+bool small_fine_cut(const verify_params& P, unsigned others) {
     const bool vargen = P.eq[0].comb == nullptr;
-    uint32_t positions = P.n <= (vargen ? SMALL_PATH_FINE_ITEMS_VARGEN : SMALL_PATH_FINE_ITEMS[P.n_eq]) ? 8 : 4;
+    return P.n <= (vargen ? SMALL_PATH_FINE_ITEMS_VARGEN : SMALL_PATH_FINE_ITEMS[P.n_eq]) && others < SMALL_ECONOMY_FROM;
+}
+uint32_t small_positions(const verify_params& P, unsigned others) {
+    uint32_t positions = small_fine_cut(P, others) ? 8 : 4;
 #if defined(JJS_PROFILING)
     if (g_force_positions) positions = (uint32_t)g_force_positions;
 #endif
-    const size_t table_bytes = P.n * sb_table_words_per_item(P.n_eq, positions) * sizeof(uint32_t);
-    if (int rc = ensure_small(table_bytes + 4 * P.n + 64)) return rc;
+    return positions;
+}
+size_t small_table_bytes(const verify_params& P, uint32_t positions) { return P.n * sb_table_words_per_item(P.n_eq, positions) * sizeof(uint32_t); }
+int launch_small(verify_params P, hipStream_t s) {
+    const bool vargen = P.eq[0].comb == nullptr;
+    const unsigned others = small_calls_in_flight();
+    const uint32_t positions = small_positions(P, others);
+    const size_t table_bytes = small_table_bytes(P, positions);
+    // (the tables of the fine cut are the larger ones: a slot sized for them holds either)
+    if (int rc = ensure_small(small_table_bytes(P, 8) + 4 * P.n + 64)) return rc;
     small_params S{};
     P.small_mode = 1;
     S.V = P;
@@ -320,7 +429,7 @@ int launch_small(verify_params P, hipStream_t s) {
     S.positions = positions;
     S.windows = vargen ? 64 : 32;
     // eight lanes per hash where the hash is the critical path (fixed generator) and the batch leaves lanes idle
-    S.hash_lanes = (!vargen && P.n <= SMALL_PATH_FINE_ITEMS[P.n_eq]) ? SB_HASH_LANES : 1;
+    S.hash_lanes = (!vargen && small_fine_cut(P, others)) ? SB_HASH_LANES : 1;
     const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);

@@ -53,24 +53,17 @@ constexpr size_t HOST_STAGING_MIN_BYTES = size_t(4) << 20;     // below this a p
 
 int ensure_stage(size_t bytes) {
     if (bytes <= g->stage_bytes) return JJS_OK;
-    if (g->stage) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(g->stage));
-        g->stage = nullptr; g->stage_bytes = 0;
-    }
-    HIP_TRY(hipMalloc(&g->stage, bytes));
-    g->stage_bytes = bytes;
-    return JJS_OK;
+    const size_t cap = grown(bytes);
+    return regrow(g->stage, g->stage_bytes, g->stage_bytes, cap, cap);
 }
 int ensure_pinned(size_t bytes) {
     if (bytes <= g->pinned_bytes) return JJS_OK;
-    if (g->pinned) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipHostFree(g->pinned));
-        g->pinned = nullptr; g->pinned_bytes = 0;
-    }
-    HIP_TRY(hipHostMalloc(&g->pinned, bytes, hipHostMallocDefault));
-    g->pinned_bytes = bytes;
+    const size_t cap = grown(bytes);
+    uint8_t* fresh = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fresh), cap, hipHostMallocDefault));
+    retire(g->pinned, true, g->pinned_bytes);
+    g->pinned = fresh;
+    g->pinned_bytes = cap;
     return JJS_OK;
 }
 
@@ -265,7 +258,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
     bool late = false;
     for (size_t k = 0; k < n_cols; ++k) late = late || cols[k].group == COLS_LATE;
-    late = late && !J.C.wire && !small_path_applies(J.C.P) && key_path_applies(J.C.P) && ensure_key_pool() == JJS_OK;
+    late = late && !J.C.wire && !small_path_applies(J.C.P) && key_path_applies(J.C.P) && ensure_key_pool(J.C.P) == JJS_OK;
 #if defined(JJS_HOST_NO_LATE)            // build-time knob of the A/B run recorded in DESIGN.md 6
     late = false;
 #endif
@@ -437,6 +430,20 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     g_host_timing[4] = t_first; g_host_timing[5] = t_queued - t_begin; g_host_timing[6] = t_drained - t_queued; g_host_timing[7] = now() - t_drained;
 #endif
     return JJS_OK;
+}
+
+// jjs_reserve: the device arena and the pinned staging a block of nl items with these columns needs (current device)
+int reserve_host_block(const host_col* cols, size_t n_cols, size_t nl, int wire_points) {
+    size_t row_keys = 0, row_rest = 0, row_late = 0, bytes = 0, largest = 256;
+    for (size_t k = 0; k < n_cols; ++k) {
+        (cols[k].group == COLS_KEYS ? row_keys : cols[k].group == COLS_LATE ? row_late : row_rest) += cols[k].width;
+        bytes += pad256(nl * cols[k].width);
+    }
+    std::vector<host_piece> plan;
+    plan_pieces(plan, largest, nl, row_keys, row_rest, row_late, wire_points, false);
+    plan_pieces(plan, largest, nl, row_keys, row_rest, row_late, wire_points, true);
+    if (int rc = ensure_stage(bytes + pad256(nl))) return rc;
+    return ensure_pinned(HOST_SLOTS * pad256(largest) + pad256(nl) + 256);
 }
 
 int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, int wire_points) {

@@ -22,6 +22,7 @@
 //   (here)             the extern "C" entry points: one staged_call builder per scheme and input format
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -135,6 +136,7 @@ int init_device(device_state& d, int ordinal) {
             HIP_TRY(hipEventCreateWithFlags(&c.key_join, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_ahead, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.key_chains, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.key_cleared, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.seen), sizeof(key_feedback), hipHostMallocDefault));
             memset(c.seen, 0, sizeof(key_feedback));
         }
@@ -184,11 +186,19 @@ void free_device(device_state& d) {
         for (void* b : sb)
             if (b) (void)hipFree(b);
         if (c.seen) (void)hipHostFree(c.seen);
-        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join, c.key_ahead, c.key_chains};
+        hipEvent_t evs[] = {c.last_use, c.key_fork, c.key_mid, c.key_join, c.key_ahead, c.key_chains, c.key_cleared};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
     if (d.pinned) (void)hipHostFree(d.pinned);
+    for (host_lane& l : d.lanes) {
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.dev) (void)hipFree(l.dev);
+        if (l.pinned) (void)hipHostFree(l.pinned);
+    }
+    (void)hipDeviceSynchronize();
+    free_retired(d);
     if (d.last_use) (void)hipEventDestroy(d.last_use);
     for (size_t i = 0; i < HOST_MAX_PIECES; ++i) {
         if (d.chunk_up[i]) (void)hipEventDestroy(d.chunk_up[i]);
@@ -204,7 +214,7 @@ void free_device(device_state& d) {
     if (d.ingest_done) (void)hipEventDestroy(d.ingest_done);
     delete d.stagers;
     if (d.stream) (void)hipStreamDestroy(d.stream);
-    d = device_state{};
+    d.device = -1;
 }
 
 int load_rccl() {
@@ -282,7 +292,7 @@ struct device_restore {   // puts the calling thread back on the device it came 
 
 extern "C" {
 
-int jjs_abi_version(void) { return 4; }
+int jjs_abi_version(void) { return 5; }
 const char* jjs_last_error(void) { return t_err; }
 
 int jjs_init(int device_count) {
@@ -322,8 +332,16 @@ int jjs_init(int device_count) {
 }
 
 void jjs_shutdown(void) {
-    std::lock_guard<std::mutex> lock(L.mu);
+    std::unique_lock<std::mutex> lock(L.mu);
+    // host-buffer calls that hold a lane finish first (they wait for the device outside the mutex)
+    L.lane_cv.wait(lock, [] {
+        for (device_state* d : L.devs)
+            for (const host_lane& l : d->lanes)
+                if (l.state != host_lane::FREE) return false;
+        return true;
+    });
     shutdown_locked();
+    L.lane_cv.notify_all();
 }
 
 int jjs_device_count(void) {
@@ -351,15 +369,8 @@ int jjs_stream_sync(void* stream) {
 // calls feed it piece by piece (run_host_block).
 static int ensure_wire(size_t n) {
     if (n <= sl->wire_items) return JJS_OK;
-    if (sl->wire) {
-        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old buffer
-        HIP_TRY(hipFree(sl->wire));
-        sl->wire = nullptr; sl->wire_items = 0;
-    }
-    size_t cap = n < 4096 ? 4096 : n;
-    HIP_TRY(hipMalloc(&sl->wire, cap * (4 * 64 + 16 + 2 * 48)));
-    sl->wire_items = cap;
-    return JJS_OK;
+    const size_t cap = grown(n < 4096 ? 4096 : n);
+    return regrow(sl->wire, sl->wire_items, sl->wire_items * (4 * 64 + 16 + 2 * 48), cap, cap * (4 * 64 + 16 + 2 * 48));
 }
 static uint8_t* wire_pts(int k) { return sl->wire + (size_t)k * sl->wire_items * 64; }
 static uint8_t* wire_bad() { return sl->wire + (size_t)4 * sl->wire_items * 64; }
@@ -512,12 +523,250 @@ static int resident_call(call_builder build, const void* const* d, size_t n, voi
     if (int rc = build(d, n, status, tally, s, C)) return rc;
     return launch_staged(C, s);
 }
+
+// The shape of every verification entry point: its builder and the columns of a host-buffer call in the order of the
+// entry point's arguments (width in bytes, and the group that decides when a large call uploads the column: host_calls.h).
+struct call_shape {
+    call_builder build;
+    size_t n_cols;
+    struct { size_t width; uint32_t group; } col[8];
+    int wire_points;              // R points per signature that a wire call decodes per item
+};
+static const call_shape SHAPES[3][3] = {       // [JJS_SCHEME_*][JJS_FORMAT_*]
+    {{build_affine_single, 4, {{32, COLS_LATE}, {64, COLS_REST}, {64, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_ext_single, 4, {{32, COLS_LATE}, {96, COLS_REST}, {96, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_wire_single, 3, {{64, COLS_REST}, {32, COLS_KEYS}, {32, COLS_REST}}, 1}},
+    {{build_affine_double, 6, {{32, COLS_LATE}, {64, COLS_REST}, {64, COLS_REST}, {64, COLS_KEYS}, {64, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_ext_double, 6, {{32, COLS_LATE}, {96, COLS_REST}, {96, COLS_REST}, {96, COLS_KEYS}, {96, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_wire_double, 3, {{96, COLS_REST}, {64, COLS_KEYS}, {32, COLS_REST}}, 2}},
+    {{build_affine_vargen, 5, {{32, COLS_LATE}, {64, COLS_REST}, {64, COLS_KEYS}, {64, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_ext_vargen, 5, {{32, COLS_LATE}, {96, COLS_REST}, {96, COLS_KEYS}, {96, COLS_KEYS}, {32, COLS_REST}}, 0},
+     {build_wire_vargen, 3, {{64, COLS_REST}, {64, COLS_KEYS}, {32, COLS_REST}}, 1}},
+};
+
+// ---- host lanes: host-buffer calls of at most LANE_MAX_ITEMS items (see host_lane) ------------------------------------
+// layout of a lane's two areas (the same in pinned host memory and on the device): one array per column, sized for `cap`
+// items, then the statuses
+struct lane_layout {
+    size_t off[8];
+    size_t in_bytes, status_off, total;
+};
+static lane_layout lane_layout_for(const call_shape& S, size_t cap) {
+    lane_layout Y{};
+    size_t p = 0;
+    for (size_t k = 0; k < S.n_cols; ++k) { Y.off[k] = p; p += pad256(cap * S.col[k].width); }
+    Y.in_bytes = p;
+    Y.status_off = p; p += pad256(cap);
+    Y.total = p;
+    return Y;
+}
+// Items a new lane is laid out for: a call too large to combine gets exactly its own; else twice what the last combined launch
+// of the shape carried (the area is uploaded whole, so it should not be much larger than what will be in it).
+static size_t lane_cap_for(const device_state* dev, int scheme, int format, size_t n) {
+    if (n > COMBINE_MAX_CALL_ITEMS) return n;
+    size_t want = 2 * (dev ? dev->lane_last_items[scheme][format] : COMBINE_CAP_ITEMS);
+    if (want < n) want = n;
+    size_t cap = 256;
+    while (cap < want) cap <<= 1;
+    return cap < COMBINE_CAP_ITEMS ? cap : COMBINE_CAP_ITEMS;
+}
+static int ensure_lane(host_lane& lane, size_t bytes) {
+    if (!lane.stream) HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+    if (!lane.done) HIP_TRY(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+    if (bytes > lane.dev_bytes) {
+        const size_t cap = grown(bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes);
+        if (int rc = regrow(lane.dev, lane.dev_bytes, lane.dev_bytes, cap, cap)) return rc;
+    }
+    if (bytes > lane.pinned_bytes) {
+        const size_t cap = grown(bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes);
+        uint8_t* fresh = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fresh), cap, hipHostMallocDefault));
+        retire(lane.pinned, true, lane.pinned_bytes);
+        lane.pinned = fresh;
+        lane.pinned_bytes = cap;
+    }
+    return JJS_OK;
+}
+// The end of a lane launch: small calls last half a millisecond, and a thread that sleeps on the stream pays the wake-up on
+// top (tens to hundreds of microseconds on an idle core), so it polls the launch's event for LANE_SPIN_US first.
+#ifndef JJS_LANE_SPIN_US
+#define JJS_LANE_SPIN_US 2000
+#endif
+static hipError_t lane_wait(host_lane& lane) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned turn = 0;; ++turn) {
+        const hipError_t e = hipEventQuery(lane.done);
+        if (e != hipErrorNotReady) return e;
+        if ((turn & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(JJS_LANE_SPIN_US)) break;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        _mm_pause();
+#endif
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(lane.stream);
+}
+// Upload, kernels and download of the lane's launch (its `items` items).  Called WITHOUT the engine's mutex (the lane is in
+// state LAUNCHED: nobody else touches it); takes the mutex for the part that uses the engine's state (slot, launches).
+static int lane_launch(device_state* dev, host_lane& lane, const call_shape& S) {
+    const lane_layout Y = lane_layout_for(S, lane.cap);
+    const size_t n = lane.items;
+    HIP_TRY(hipSetDevice(dev->device));
+    HIP_TRY(hipMemcpyAsync(lane.dev, lane.pinned, Y.in_bytes, hipMemcpyHostToDevice, lane.stream));      // one copy: the area is at most ~2 x what is in it
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        g = dev;
+        const void* in[8];
+        for (size_t k = 0; k < S.n_cols; ++k) in[k] = lane.dev + Y.off[k];
+        staged_call C;
+        // no device tally: every member counts its own statuses
+        if (int r = S.build(in, n, lane.dev + Y.status_off, nullptr, lane.stream, C)) return r;
+        if (int r = launch_staged(C, lane.stream)) return r;
+    }
+    HIP_TRY(hipMemcpyAsync(lane.pinned + Y.status_off, lane.dev + Y.status_off, n, hipMemcpyDeviceToHost, lane.stream));
+    HIP_TRY(hipEventRecord(lane.done, lane.stream));
+    return JJS_OK;
+}
+// Waiting for another thread's word: poll the epoch for LANE_SPIN_US (the waits are fractions of a millisecond, and a sleeping
+// thread would come back too late to share the next launch), then sleep on the condition variable.
+static void lane_wait_change(std::unique_lock<std::mutex>& lock, device_state* dev) {
+    const uint64_t e = dev->lane_epoch.load(std::memory_order_relaxed);
+    lock.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned turn = 0; dev->lane_epoch.load(std::memory_order_acquire) == e; ++turn) {
+        if ((turn & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(JJS_LANE_SPIN_US)) break;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        _mm_pause();
+#endif
+    }
+    lock.lock();
+    L.lane_cv.wait(lock, [&] { return dev->lane_epoch.load(std::memory_order_relaxed) != e; });
+}
+static void lane_changed(device_state* dev) {          // under the engine's mutex
+    dev->lane_epoch.fetch_add(1, std::memory_order_release);
+    L.lane_cv.notify_all();
+}
+// One call.  It joins the lane that is filling for its shape or opens one; copies its columns into the lane's pinned area
+// (outside the mutex); then whichever member finds the lane complete (nobody copying) and no other launch of the shape
+// running sends it off and waits for it; the others wait for that member's word.
+static int lane_call(int scheme, int format, const uint8_t* const* cols, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const call_shape& S = SHAPES[scheme][format];
+    const bool combinable = n <= COMBINE_MAX_CALL_ITEMS;
+    device_state* dev = nullptr;
+    host_lane* lane = nullptr;
+    std::unique_lock<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    dev = g;
+    for (;;) {
+        host_lane* free_lane = nullptr;
+        for (host_lane& l : dev->lanes) {
+            if (combinable && l.state == host_lane::OPEN && l.combinable && l.scheme == scheme && l.format == format && l.items + n <= l.cap) { lane = &l; break; }
+            if (l.state == host_lane::FREE && !free_lane) free_lane = &l;
+        }
+        if (!lane && free_lane) {
+            const size_t cap = lane_cap_for(dev, scheme, format, n);
+            if (int rc = ensure_lane(*free_lane, lane_layout_for(S, cap).total)) return rc;
+            lane = free_lane;
+            lane->state = host_lane::OPEN; lane->scheme = scheme; lane->format = format; lane->combinable = combinable;
+            lane->cap = cap; lane->items = 0; lane->copying = 0; lane->members = 0; lane->rc = JJS_OK; lane->err[0] = 0;
+            lane->gather_until = std::chrono::steady_clock::now();
+        }
+        if (lane) break;
+        lane_wait_change(lock, dev);
+        if (L.devs.empty() || check_ready() != JJS_OK || g != dev) return fail(JJS_ERR_NOT_INIT, "the engine was shut down during the call");
+    }
+    const size_t first = lane->items;
+    lane->items += n;
+    ++lane->members;
+    ++lane->copying;
+    if (lane->items == lane->cap) lane->combinable = false;        // full
+    const lane_layout Y = lane_layout_for(S, lane->cap);
+    lock.unlock();
+    for (size_t k = 0; k < S.n_cols; ++k) memcpy(lane->pinned + Y.off[k] + first * S.col[k].width, cols[k], n * S.col[k].width);
+    lock.lock();
+    if (--lane->copying == 0) lane_changed(dev);
+    while (lane->state != host_lane::DONE) {
+        // combined launches of one shape run one at a time (everything else: side by side)
+        bool shape_busy = false;
+        if (combinable)
+            for (const host_lane& l : dev->lanes)
+                shape_busy = shape_busy || (&l != lane && l.state == host_lane::LAUNCHED && l.combinable_shape && l.scheme == scheme && l.format == format);
+        if (lane->state == host_lane::OPEN && lane->copying == 0 && !shape_busy) {
+            const auto until = lane->gather_until;
+            if (lane->combinable && std::chrono::steady_clock::now() < until) {
+                // callers that are on their way may still join (a short spin: the timers of a sleeping wait are coarser than this)
+                lock.unlock();
+                while (std::chrono::steady_clock::now() < until) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+                    _mm_pause();
+#endif
+                }
+                lock.lock();
+                continue;
+            }
+            lane->state = host_lane::LAUNCHED;            // closed: its items are final
+            lane->combinable_shape = combinable;
+            ++dev->stats[JJS_PATH_LANE_LAUNCHES];
+            dev->stats[JJS_PATH_LANE_CALLS] += lane->members;
+            lane_changed(dev);
+            lock.unlock();
+            int rc = no_throw([&] { return lane_launch(dev, *lane, S); });
+            // whatever was queued drains before anybody touches the lane again, also after a failure
+            const hipError_t e = rc == JJS_OK ? lane_wait(*lane) : hipStreamSynchronize(lane->stream);
+            if (rc == JJS_OK && e != hipSuccess) rc = fail(JJS_ERR_HIP, "waiting for the launch: %s", hipGetErrorString(e));
+            lock.lock();
+            lane->rc = rc;
+            if (rc != JJS_OK) snprintf(lane->err, sizeof(lane->err), "%s", t_err);
+            lane->state = host_lane::DONE;
+            if (combinable) {
+                dev->lane_last_items[scheme][format] = lane->items;
+                // the lane that filled behind this launch waits a moment for the callers this launch is about to release
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(COMBINE_WINDOW_US);
+                for (host_lane& l : dev->lanes)
+                    if (l.state == host_lane::OPEN && l.scheme == scheme && l.format == format) l.gather_until = until;
+            }
+            lane_changed(dev);
+            break;
+        }
+        lane_wait_change(lock, dev);
+    }
+    int rc = lane->rc;
+    if (rc != JJS_OK) rc = fail(rc, "%s", lane->err);
+    else {
+        const uint8_t* st = lane->pinned + Y.status_off + first;
+        lock.unlock();
+        if (status) memcpy(status, st, n);
+        if (tally) {
+            uint64_t t[256] = {};
+            for (size_t i = 0; i < n; ++i) ++t[st[i]];
+            for (int k = 0; k < 4; ++k) tally[k] = t[k];
+        }
+        lock.lock();
+    }
+    if (--lane->members == 0) { lane->state = host_lane::FREE; lane_changed(dev); }
+    return rc;
+}
+
 // a host-buffer call: blocking
-static int host_call(call_builder build, const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4],
-                     int wire_points = 0) {
+static int host_call(int scheme, int format, const uint8_t* const* ptrs, size_t n, uint8_t* status, uint64_t tally[4]) {
+    const call_shape& S = SHAPES[scheme][format];
+    for (size_t k = 0; k < S.n_cols; ++k)
+        if (n && !ptrs[k]) return fail(JJS_ERR_ARG, "null input pointer");
+    bool one_device = false;
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        if (int rc = check_ready()) return rc;
+        one_device = L.devs.size() == 1;
+    }
+    if (n == 0) {
+        if (tally) for (int k = 0; k < 4; ++k) tally[k] = 0;
+        return JJS_OK;
+    }
+    if (one_device && n <= LANE_MAX_ITEMS) return lane_call(scheme, format, ptrs, n, status, tally);
     std::lock_guard<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
-    return no_throw([&] { return run_host(cols, n_cols, n, status, tally, build, wire_points); });
+    host_col cols[8];
+    for (size_t k = 0; k < S.n_cols; ++k) cols[k] = host_col{ptrs[k], S.col[k].width, S.col[k].group};
+    return no_throw([&] { return run_host(cols, S.n_cols, n, status, tally, S.build, S.wire_points); });
 }
 
 // ---- affine inputs: device-buffer and host-buffer entry points ----------------------------------------------
@@ -538,18 +787,18 @@ int jjs_verify_vargen_dev(const void* u, const void* R, const void* PK, const vo
 }
 int jjs_verify_single(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n,
                       uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_affine_single, cols, 4, n, status, tally);
+    const uint8_t* p[] = {u, R, PK, m};
+    return host_call(JJS_SCHEME_SINGLE, JJS_FORMAT_AFFINE, p, n, status, tally);
 }
 int jjs_verify_double(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
                       const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {Rp, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {PKp, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_affine_double, cols, 6, n, status, tally);
+    const uint8_t* p[] = {u, R, Rp, PK, PKp, m};
+    return host_call(JJS_SCHEME_DOUBLE, JJS_FORMAT_AFFINE, p, n, status, tally);
 }
 int jjs_verify_vargen(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m,
                       size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 64, COLS_REST}, {PK, 64, COLS_KEYS}, {Gen, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_affine_vargen, cols, 5, n, status, tally);
+    const uint8_t* p[] = {u, R, PK, Gen, m};
+    return host_call(JJS_SCHEME_VARGEN, JJS_FORMAT_AFFINE, p, n, status, tally);
 }
 
 // ---- wire formats: on-device decoding, then the same verify kernels -----------------------------------
@@ -566,16 +815,16 @@ int jjs_verify_vargen_wire_dev(const void* sig, const void* pk, const void* m, s
     return resident_call(build_wire_vargen, d, n, status, tally, stream);
 }
 int jjs_verify_single_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 32, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_single, cols, 3, n, status, tally, 1);
+    const uint8_t* p[] = {sig, pk, m};
+    return host_call(JJS_SCHEME_SINGLE, JJS_FORMAT_WIRE, p, n, status, tally);
 }
 int jjs_verify_double_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 96, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_double, cols, 3, n, status, tally, 2);
+    const uint8_t* p[] = {sig, pk, m};
+    return host_call(JJS_SCHEME_DOUBLE, JJS_FORMAT_WIRE, p, n, status, tally);
 }
 int jjs_verify_vargen_wire(const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{sig, 64, COLS_REST}, {pk, 64, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_wire_vargen, cols, 3, n, status, tally, 1);
+    const uint8_t* p[] = {sig, pk, m};
+    return host_call(JJS_SCHEME_VARGEN, JJS_FORMAT_WIRE, p, n, status, tally);
 }
 
 // ---- extended coordinates (U, V, Z): normalised on the device, then the same verify kernels -----------------
@@ -596,18 +845,107 @@ int jjs_verify_vargen_ext_dev(const void* u, const void* R, const void* PK, cons
 }
 int jjs_verify_single_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* m, size_t n, uint8_t* status,
                           uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_ext_single, cols, 4, n, status, tally);
+    const uint8_t* p[] = {u, R, PK, m};
+    return host_call(JJS_SCHEME_SINGLE, JJS_FORMAT_EXT, p, n, status, tally);
 }
 int jjs_verify_double_ext(const uint8_t* u, const uint8_t* R, const uint8_t* Rp, const uint8_t* PK, const uint8_t* PKp,
                           const uint8_t* m, size_t n, uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {Rp, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {PKp, 96, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_ext_double, cols, 6, n, status, tally);
+    const uint8_t* p[] = {u, R, Rp, PK, PKp, m};
+    return host_call(JJS_SCHEME_DOUBLE, JJS_FORMAT_EXT, p, n, status, tally);
 }
 int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R, const uint8_t* PK, const uint8_t* Gen, const uint8_t* m, size_t n,
                           uint8_t* status, uint64_t tally[4]) {
-    const host_col cols[] = {{u, 32, COLS_LATE}, {R, 96, COLS_REST}, {PK, 96, COLS_KEYS}, {Gen, 96, COLS_KEYS}, {m, 32, COLS_REST}};
-    return host_call(build_ext_vargen, cols, 5, n, status, tally);
+    const uint8_t* p[] = {u, R, PK, Gen, m};
+    return host_call(JJS_SCHEME_VARGEN, JJS_FORMAT_EXT, p, n, status, tally);
+}
+
+// ---- pre-sizing and trimming ------------------------------------------------------------------------------------
+// What a call of this shape and size would allocate on first use, allocated now, in EVERY slot (and lane) such a call can
+// land in: a service calls this once per call shape at start-up and no later call of at most that size allocates.
+int jjs_reserve(int scheme, int format, size_t n_items, int host_buffers) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (scheme < 0 || scheme > 2 || format < 0 || format > 2) return fail(JJS_ERR_ARG, "scheme / format out of range");
+    if (n_items == 0) return JJS_OK;
+    const call_shape& S = SHAPES[scheme][format];
+    return no_throw([&]() -> int {
+        device_restore restore;
+        std::vector<device_state*> targets;
+        if (L.devs.size() == 1 || !host_buffers) targets.push_back(g); else targets = L.devs;
+        size_t per = host_buffers ? (n_items + targets.size() - 1) / targets.size() : n_items;
+        // small host-buffer calls combine: the launch their slot sees may carry up to COMBINE_CAP_ITEMS items
+        const size_t call_items = per;
+        if (host_buffers && targets.size() == 1 && per <= COMBINE_MAX_CALL_ITEMS) per = COMBINE_CAP_ITEMS;
+        for (device_state* d : targets) {
+            g = d;
+            HIP_TRY(hipSetDevice(d->device));
+            int lo, hi;
+            if (per <= SMALL_SLOT_ITEMS) { lo = 1; hi = N_SMALL_SLOTS; }
+            else if (per <= MEDIUM_SLOT_ITEMS) { lo = 1 + N_SMALL_SLOTS; hi = N_SMALL_SLOTS + N_MEDIUM_SLOTS; }
+            else { lo = 0; hi = SECOND_BIG_SLOT; }
+            for (int i = lo; i <= hi; ++i) {
+                if (lo == 0 && i != 0 && i != SECOND_BIG_SLOT) continue;
+                forced_slot = &d->slots[i];
+                // the builder sizes what the format needs in the slot; its descriptors (built from a placeholder address,
+                // never dereferenced) tell which path the call would take
+                const void* in[8];
+                for (size_t k = 0; k < S.n_cols; ++k) in[k] = reinterpret_cast<const void*>(uintptr_t(4096));
+                staged_call C;
+                int rc = S.build(in, per, nullptr, nullptr, nullptr, C);
+                forced_slot = nullptr;
+                if (rc) return rc;
+                if (int r = reserve_for(C.P)) return r;
+            }
+            if (host_buffers) {
+                if (targets.size() == 1 && per <= LANE_MAX_ITEMS) {
+                    const lane_layout Y = lane_layout_for(S, lane_cap_for(nullptr, scheme, format, call_items));
+                    for (host_lane& l : d->lanes)
+                        if (int r = ensure_lane(l, Y.total)) return r;
+                } else {
+                    host_col cols[8];
+                    for (size_t k = 0; k < S.n_cols; ++k) cols[k] = host_col{nullptr, S.col[k].width, S.col[k].group};
+                    if (int r = reserve_host_block(cols, S.n_cols, per, S.wire_points)) return r;
+                }
+            }
+        }
+        g = targets[0];
+        return JJS_OK;
+    });
+}
+// Waits for the devices to go idle, then frees what growth has retired and every slot's key-table pool (a later call that
+// takes the key tables allocates its pool again, at the size the slot had learnt).
+int jjs_trim(void) {
+    std::unique_lock<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    device_restore restore;
+    for (device_state* d : L.devs) {
+        HIP_TRY(hipSetDevice(d->device));
+        HIP_TRY(hipDeviceSynchronize());
+        free_retired(*d);
+        for (call_slot& c : d->slots) {
+            if (!c.key_pool) continue;
+            HIP_TRY(hipFree(c.key_pool));
+            if (c.key_pool_bytes > c.key_pool_want) c.key_pool_want = c.key_pool_bytes;
+            c.key_pool = nullptr; c.key_pool_bytes = 0;
+        }
+    }
+    return JJS_OK;
+}
+int jjs_memory_stats(uint64_t out[JJS_MEMORY_STATS]) {
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
+    if (!out) return fail(JJS_ERR_ARG, "null pointer");
+    uint64_t pool = 0, slots = 0, lanes = 0;
+    for (const call_slot& c : g->slots) {
+        pool += c.key_pool_bytes;
+        slots += c.pending_items * 8 + c.prep_items * 65 + c.wire_items * (4 * 64 + 16 + 2 * 48) + c.small_bytes + c.keys_bytes;
+    }
+    for (const host_lane& l : g->lanes) lanes += l.dev_bytes + l.pinned_bytes;
+    out[JJS_MEMORY_KEY_POOLS] = pool;
+    out[JJS_MEMORY_SLOT_BUFFERS] = slots;
+    out[JJS_MEMORY_HOST_STAGING] = lanes + g->stage_bytes + g->pinned_bytes;
+    out[JJS_MEMORY_RETIRED] = g->retired_bytes;
+    return JJS_OK;
 }
 
 // Which method the calls on the current device took (include/jjs_gpu.h).  Calls that tried the key tables are counted
@@ -684,9 +1022,13 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     if ((n && !all_ok(z, PK, R, S)) || !all_ok(m, agg_pk, sig_u, sig_R) || (n && !share_status)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     if (n > g->msig_items || n_transcripts > g->msig_transcripts) {
-        if (g->msig) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->msig)); g->msig = nullptr; }
-        size_t ci = n < 4096 ? 4096 : n, ct = n_transcripts < 1024 ? 1024 : n_transcripts;
-        HIP_TRY(hipMalloc(&g->msig, ci * 4 * (1 + 8 + 2 * EXT_WORDS) + ct * 4 * (16 + 1 + 18) + 64));
+        size_t ci = grown(n < 4096 ? 4096 : n), ct = grown(n_transcripts < 1024 ? 1024 : n_transcripts);
+        if (ci < g->msig_items) ci = g->msig_items;
+        if (ct < g->msig_transcripts) ct = g->msig_transcripts;
+        uint8_t* fresh = nullptr;
+        HIP_TRY(hipMalloc(&fresh, ci * 4 * (1 + 8 + 2 * EXT_WORDS) + ct * 4 * (16 + 1 + 18) + 64));
+        retire(g->msig, false, g->msig_items * 4 * (1 + 8 + 2 * EXT_WORDS) + g->msig_transcripts * 4 * (16 + 1 + 18) + 64);
+        g->msig = fresh;
         g->msig_items = ci; g->msig_transcripts = ct;
     }
     msig_params P{};

@@ -73,25 +73,37 @@ void note_key_feedback() {
 
 int ensure_key_index(size_t bytes) {
     if (bytes <= sl->keys_bytes) return JJS_OK;
-    if (sl->keys) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(sl->keys));
-        sl->keys = nullptr; sl->keys_bytes = 0;
-    }
-    HIP_TRY(hipMalloc(&sl->keys, bytes));
-    sl->keys_bytes = bytes;
-    return JJS_OK;
+    const size_t cap = grown(bytes);
+    return regrow(sl->keys, sl->keys_bytes, sl->keys_bytes, cap, cap);
 }
-// The pool grows when a call has asked for more; when hipMalloc says no, the pool the slot has stays (and that size
-// is not asked for again).  Nothing is freed before its replacement exists.
-int ensure_key_pool() {
+// key columns of a scheme: PK of every equation, and the generator where it is per-item data
+uint32_t key_columns(const verify_params& P, fe_src cols[2]) {
+    uint32_t n_cols = 0;
+    for (uint32_t e = 0; e < P.n_eq; ++e) {
+        if (cols) cols[P.eq[e].pk_col] = P.eq[e].pk;
+        n_cols = n_cols > (uint32_t)P.eq[e].pk_col + 1 ? n_cols : (uint32_t)P.eq[e].pk_col + 1;
+        if (!P.eq[e].comb) {
+            if (cols) cols[P.eq[e].gen_col] = P.eq[e].gen;
+            n_cols = n_cols > (uint32_t)P.eq[e].gen_col + 1 ? n_cols : (uint32_t)P.eq[e].gen_col + 1;
+        }
+    }
+    return n_cols;
+}
+// The pool is sized by the call at hand -- no batch takes the path with more than n / 16 keys per column, so a medium slot's
+// single-column calls never ask for more than ~1.1 GB -- up to KEY_POOL_INITIAL_BYTES, and beyond that only when a call has
+// shown that its keys repeat and need more (key_pool_want).  When hipMalloc says no, the pool the slot has stays (and that
+// size is not asked for again).  The replacement exists before the old pool is retired; nobody waits for the device.
+int ensure_key_pool(const verify_params& P) {
 #if defined(JJS_PROFILING)
     if (g_fail_key_arena) return fail(JJS_ERR_HIP, "key arena allocation failed (jjs_debug_fail_key_arena)");
 #endif
-    size_t want = sl->key_pool_want > KEY_POOL_INITIAL_BYTES ? sl->key_pool_want : KEY_POOL_INITIAL_BYTES;
+    const uint32_t n_cols = key_columns(P, nullptr);
+    size_t first = key_pool_bytes_for(n_cols ? n_cols : 1, P.n / KT_MIN_MULTIPLICITY, false);
+    if (first > KEY_POOL_INITIAL_BYTES) first = KEY_POOL_INITIAL_BYTES;
+    size_t want = sl->key_pool_want > first ? sl->key_pool_want : first;
     const bool refused = sl->key_pool_refused && want >= sl->key_pool_refused;     // hipMalloc has said no to this much before
     if (sl->key_pool && (want <= sl->key_pool_bytes || refused)) return JJS_OK;
-    if (!sl->key_pool && refused) want = KEY_POOL_INITIAL_BYTES;
+    if (!sl->key_pool && refused) want = first < sl->key_pool_refused ? first : sl->key_pool_refused / 2;
     uint8_t* fresh = nullptr;
     if (hipMalloc(&fresh, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -99,10 +111,7 @@ int ensure_key_pool() {
         ++g->stats[JJS_PATH_KEYS_NO_MEMORY];
         return sl->key_pool ? JJS_OK : fail(JJS_ERR_HIP, "hipMalloc of the key-table pool (%zu bytes) failed", want);
     }
-    if (sl->key_pool) {
-        HIP_TRY(hipDeviceSynchronize());        // earlier launches may still read the old pool
-        HIP_TRY(hipFree(sl->key_pool));
-    }
+    retire(sl->key_pool, false, sl->key_pool_bytes);        // earlier launches may still read the old pool
     sl->key_pool = fresh;
     sl->key_pool_bytes = want;
     return JJS_OK;
@@ -126,32 +135,23 @@ struct wire_keys {
     decode_params sig{};     // the R points of the signatures (decoded per item, beside the key kernels)
 };
 uint64_t next_seed() {       // per-call seed of the dedup hash: unpredictable to whoever chose the keys
+    static std::mutex mu;    // the per-device workers of a multi-device host call get here concurrently
     static std::mt19937_64 rng = [] {
         std::random_device rd;
         std::seed_seq seq{rd(), rd(), rd(), rd(), (unsigned)std::chrono::steady_clock::now().time_since_epoch().count()};
         return std::mt19937_64(seq);
     }();
+    std::lock_guard<std::mutex> lock(mu);
     return rng();
 }
-// Carves the key buffers of this call out of the slot's two arenas and clears the hash tables and counters (on `s`).
-int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
-    note_key_feedback();
+// Carves the key buffers of this call out of the slot's two arenas (growing them if need be); what the call must find
+// cleared -- counters, cursors, the hash table of every column -- lies side by side at [*cleared, *cleared + *cleared_bytes).
+int carve_keys(const verify_params& P, key_params& K, uint8_t** cleared, size_t* cleared_bytes) {
     K.n = P.n;
-    K.seed = next_seed();
-#if defined(JJS_PROFILING)
-    K.force_window = (uint32_t)g_force_window;
-    K.keep_order = g_keep_order ? 1u : 0u;
-    if (g_pin_hash_seed) K.seed = 0;
-#endif
-    // key columns: PK of every equation, and the generator where it is per-item data
     fe_src cols[2];
-    uint32_t n_cols = 0;
-    for (uint32_t e = 0; e < P.n_eq; ++e) {
-        cols[P.eq[e].pk_col] = P.eq[e].pk; n_cols = n_cols > (uint32_t)P.eq[e].pk_col + 1 ? n_cols : (uint32_t)P.eq[e].pk_col + 1;
-        if (!P.eq[e].comb) { cols[P.eq[e].gen_col] = P.eq[e].gen; n_cols = n_cols > (uint32_t)P.eq[e].gen_col + 1 ? n_cols : (uint32_t)P.eq[e].gen_col + 1; }
-    }
+    const uint32_t n_cols = key_columns(P, cols);
     K.n_cols = n_cols;
-    if (int rc = ensure_key_pool()) return rc;
+    if (int rc = ensure_key_pool(P)) return rc;
     const size_t col_bytes = (sl->key_pool_bytes / n_cols) & ~size_t(255);
     const pool_layout L = key_pool_layout(col_bytes);
     const uint64_t most = P.n / KT_MIN_MULTIPLICITY;            // more keys than this never take the path
@@ -166,14 +166,14 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     if (int rc = ensure_key_index(256 + order_bytes + n_cols * per_col)) return rc;
     uint8_t* p = sl->keys;
     // what every call finds cleared comes first and side by side (one memset, one launch: the dozen small dependent launches at
-    // the head of a call are a third of a 2^16-item batch): counters, cursors, the hash table of every column
-    uint8_t* const cleared = p;
+    // the head of a call are a third of a 2^16-item batch)
+    *cleared = p;
     K.counters = reinterpret_cast<uint32_t*>(p); p += 256;
     K.key_cursor = reinterpret_cast<uint32_t*>(p); p += pad256(cursor_words * 4);
     for (uint32_t c = 0; c < n_cols; ++c) {
         K.col[c].hash = reinterpret_cast<uint32_t*>(p); K.col[c].hash_mask = (uint32_t)(slots - 1); p += pad256(slots * 4);
     }
-    HIP_TRY(hipMemsetAsync(cleared, 0, (size_t)(p - cleared), s));
+    *cleared_bytes = (size_t)(p - *cleared);
     K.order = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
     for (uint32_t c = 0; c < n_cols; ++c) {
         key_column& C = K.col[c];
@@ -190,6 +190,21 @@ int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
     }
     return JJS_OK;
 }
+// The key buffers of this call, and their clearing on `s`.
+int setup_keys(const verify_params& P, key_params& K, hipStream_t s) {
+    note_key_feedback();
+    K.seed = next_seed();
+#if defined(JJS_PROFILING)
+    K.force_window = (uint32_t)g_force_window;
+    K.keep_order = g_keep_order ? 1u : 0u;
+    if (g_pin_hash_seed) K.seed = 0;
+#endif
+    uint8_t* cleared = nullptr;
+    size_t cleared_bytes = 0;
+    if (int rc = carve_keys(P, K, &cleared, &cleared_bytes)) return rc;
+    HIP_TRY(hipMemsetAsync(cleared, 0, cleared_bytes, s));
+    return JJS_OK;
+}
 
 bool small_path_applies(const verify_params& P) {
     if (P.n_eq < 1 || P.n_eq > 2) return false;
@@ -202,6 +217,20 @@ bool small_path_applies(const verify_params& P) {
     if (g_force_path == 2) return P.n <= MEDIUM_SLOT_ITEMS;
 #endif
     return P.n <= (vargen ? SMALL_PATH_MAX_ITEMS_VARGEN : SMALL_PATH_MAX_ITEMS[P.n_eq]);
+}
+
+// jjs_reserve: the slot buffers a call with this descriptor would allocate (the slot is `sl`), allocated now
+int reserve_for(const verify_params& P) {
+    if (int rc = ensure_prep(P.n)) return rc;
+    if (small_path_applies(P)) return ensure_small(small_table_bytes(P, 8) + 4 * P.n + 64);
+    if (int rc = ensure_pending(P.n)) return rc;
+    if (key_path_applies(P)) {
+        key_params K{};
+        uint8_t* cleared = nullptr;
+        size_t cleared_bytes = 0;
+        if (carve_keys(P, K, &cleared, &cleared_bytes) != JJS_OK) (void)hipGetLastError();     // as in a call: no pool, no key tables
+    }
+    return JJS_OK;
 }
 
 // ---- one verification call, in stages --------------------------------------------------------------------
@@ -221,6 +250,7 @@ bool small_path_applies(const verify_params& P) {
 enum : uint32_t { COLS_KEYS = 1, COLS_REST = 2, COLS_ALL = 3, COLS_LATE = 4 };
 struct staged_call {
     verify_params P{};
+    bool tally_cleared = false;       // the caller's counters arrive zeroed (a lane call uploads them with its inputs)
     bool wire = false;                // compressed points: W
     wire_keys W{};
     bool ext = false;                 // extended points: N[COLS_KEYS] the key columns, N[COLS_REST] the others, N[COLS_ALL] all
@@ -280,7 +310,7 @@ int job_begin(verify_job& J, hipStream_t s) {
     if (int rc = begin_shared(s)) return rc;
     J.open = true;
     clear_params Z{};
-    Z.p[0] = P.tally; Z.bytes[0] = P.tally ? 4 * sizeof(unsigned long long) : 0;
+    Z.p[0] = P.tally; Z.bytes[0] = P.tally && !J.C.tally_cleared ? 4 * sizeof(unsigned long long) : 0;
     Z.p[1] = const_cast<uint8_t*>(P.pre_malformed); Z.bytes[1] = P.pre_malformed ? P.n : 0;
     J.small = small_path_applies(P);
     if (!J.small) {
@@ -312,6 +342,16 @@ int job_begin(verify_job& J, hipStream_t s) {
         return JJS_OK;
     }
     P.key_flag = J.K.counters + 2;
+    // A launch that reads the decision word must find this call's cleared word or this call's decision, never what the slot's
+    // previous call left there.  A resident call's readers are ordered behind the key stream anyway (PREP_HEAD does not read the
+    // word; a wire call hashes behind key_mid; PREP_TAIL and the equations run behind key_join).  A host-buffer call hashes its
+    // first ranges before its key kernels are even queued, and a wire call does so with PREP_ALL, which reads the word: a stale
+    // non-zero value would give those items records without half-size scalars and without validated keys.  So its streams --
+    // all forked from `s` behind this point -- start behind the clearing (its first upload takes longer than that anyway).
+    if (J.host_fed) {
+        HIP_TRY(hipEventRecord(sl->key_cleared, sl->key_stream));
+        HIP_TRY(hipStreamWaitEvent(s, sl->key_cleared, 0));
+    }
 #if defined(JJS_AB_NO_SPLIT)        // build-time knob of the A/B run recorded in DESIGN.md 6
     J.split = false;
 #else

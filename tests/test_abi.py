@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.jjs_abi_version() == 4
+    assert lib.jjs_abi_version() == 5
 
 
 def exported(path):

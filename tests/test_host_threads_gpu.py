@@ -1,0 +1,189 @@
+"""The blocking host-buffer entry points under the reference's own call pattern: few signatures per call, many host
+threads (the reference API verifies one item per call, /root/reference/src/keys/public.rs:114-118; its callers are
+services with a thread per request).  Calls of at most 131 072 items take a staging lane each and hold the engine's
+mutex only while they are queued (csrc/jjs_gpu.hip lane_call), so they run side by side on the device.
+
+Also here: what keeps an asynchronous call asynchronous (no device-wide wait when a buffer grows, jjs_reserve), and the
+ordering of the key-table decision word between two host-buffer wire calls in one slot."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from helpers import ARG_ORDER, batch_to_extended, make_batch, oracle_verify, to_wire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available()
+    import jubjub_schnorr_amd as jjs
+    return jjs.engine()
+
+
+def _call(eng, scheme, fmt, args):
+    if fmt == "affine":
+        return eng.verify(scheme, *args)
+    return eng.verify_ext(scheme, *args) if fmt == "ext" else eng.verify_wire(scheme, *args)
+
+
+def _mixed_work(n):
+    specs = [("single", "affine"), ("double", "affine"), ("vargen", "wire"), ("single", "ext"), ("single", "wire"), ("double", "ext")]
+    work = []
+    for i, (scheme, fmt) in enumerate(specs):
+        b = make_batch(scheme, n, seed=4100 + i, n_keys=16)
+        want = oracle_verify(scheme, b)
+        args = {"affine": [b[k] for k in ARG_ORDER[scheme]], "ext": batch_to_extended(scheme, b, seed=i),
+                "wire": list(to_wire(scheme, b))}[fmt]
+        work.append((scheme, fmt, [np.ascontiguousarray(a) for a in args], want))
+        assert set(want.tolist()) >= {0, 1, 2}
+    return work
+
+
+def test_four_threads_of_small_host_calls_against_the_oracle(eng, tmp_path):
+    """4 host threads x 200 blocking calls of 1 024 mixed items each (every scheme, every input format among them), every
+    status of every call against the C oracle -- from python threads, and from a C program with pthreads (tests/c/
+    thread_client.c: no interpreter lock between the callers, what a service written in the reference's language sees).
+    And the threads overlap: with 4 threads the engine completes at least 2.5 x the calls per second of one thread."""
+    from jubjub_schnorr_amd.tools.small_host_calls import build_thread_client, c_threads, write_batches
+    n, calls = 1024, 200
+    work = _mixed_work(n)
+    for scheme, fmt, args, want in work:            # first calls: buffers grow, lanes are created
+        st, tally = _call(eng, scheme, fmt, args)
+        assert (st == want).all() and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+
+    bad, start = [], threading.Barrier(5)
+
+    def run(t):
+        mine = work[t:] + work[:t]                  # every thread cycles through all six shapes, out of phase with the others
+        start.wait()
+        for c in range(calls):
+            scheme, fmt, args, want = mine[c % len(mine)]
+            st, tally = _call(eng, scheme, fmt, args)
+            if not ((st == want).all() and tally.tolist() == [int((want == k).sum()) for k in range(4)]):
+                bad.append((t, c, scheme, fmt))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    start.wait()
+    for th in threads:
+        th.join()
+    assert not bad, bad[:5]
+
+    exe = build_thread_client(str(tmp_path))
+    mixed = str(tmp_path / "mixed.bin")
+    write_batches(mixed, work)
+    rec = c_threads(exe, mixed, [4], calls, rotate=True)[0]              # the same six shapes from four pthreads
+    assert rec["mismatches"] == 0 and rec["errors"] == 0, rec
+    same = str(tmp_path / "single.bin")
+    # the rate: 1 024 single signatures per call (four batches of the same shape, statuses from the oracle), 1 and 4 threads
+    singles = [work[0]]
+    for i in range(3):
+        b = make_batch("single", n, seed=4200 + i, n_keys=16)
+        singles.append(("single", "affine", [b[k] for k in ARG_ORDER["single"]], oracle_verify("single", b)))
+    write_batches(same, singles)
+    one, four = c_threads(exe, same, [1, 4], calls)
+    assert one["mismatches"] == 0 and four["mismatches"] == 0 and one["errors"] == 0 and four["errors"] == 0
+    print(f"calls/s of 1 024 single signatures (C client): 1 thread {one['calls_per_s']:.0f}, 4 threads {four['calls_per_s']:.0f} "
+          f"({four['calls_per_s'] / one['calls_per_s']:.2f} x), {four['lane_calls'] / max(1, four['lane_launches']):.2f} calls per launch; "
+          f"six shapes in turn, 4 threads: {rec['calls_per_s']:.0f}")
+    assert four["calls_per_s"] >= 2.5 * one["calls_per_s"], (one, four)
+    assert four["lane_calls"] == 4 * calls and four["lane_launches"] < four["lane_calls"]       # calls shared launches
+
+
+@pytest.mark.parametrize("n", [1, 64, 4096, 16385, 131072])
+def test_lane_calls_of_every_size_class(eng, n):
+    """One item, a wave, the largest 8-piece latency call, the first medium size, the largest lane call: statuses of the host
+    call equal those of the resident call of the same items (which the parity suite pins to the oracle) and, up to 4 096
+    items, the oracle's."""
+    import torch
+    for scheme in ("single", "double", "vargen"):
+        if n > 4096:
+            import bench
+            arrays, expect = bench.make_inputs(eng, scheme, n, 3, n_keys=max(2, n // 64))
+            host = [arrays[k].cpu().numpy() for k in ARG_ORDER[scheme]]
+            want = expect.cpu().numpy()
+        else:
+            b = make_batch(scheme, n, seed=77 + n, n_keys=8)
+            host = [b[k] for k in ARG_ORDER[scheme]]
+            want = oracle_verify(scheme, b)
+        st, tally = eng.verify(scheme, *host)
+        assert (st == want).all(), (scheme, n, np.where(st != want)[0][:8])
+        assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+        st_d, _ = eng.verify(scheme, *[torch.from_numpy(a).cuda() for a in host])
+        assert (st_d.cpu().numpy() == want).all()
+
+
+def test_host_wire_call_with_unique_keys_after_one_with_repeating_keys(eng):
+    """Two host-buffer wire calls in one call slot, back to back: the first leaves the slot's decision word at `key tables,
+    wide windows`, the second -- keys that do not repeat -- hashes its first ranges before its own key kernels are queued
+    (PREP_ALL reads the word).  Those ranges must find the word cleared, not the first call's decision: a stale read would
+    give them records without half-size scalars and without validated keys.  Statuses by construction (GPU signer, pinned to
+    the oracle by test_gpu_signer_matches_oracle), invalid keys among the items of the leading ranges."""
+    import bench
+    import torch
+    n = 3 << 17                                  # a large host call: the piece-by-piece pipeline, leading ranges of 2^16 and 2^17 items
+    for scheme in ("single", "vargen"):
+        rep, want_rep = bench.make_inputs(eng, scheme, n, 11)                    # 4 096 keys: key tables
+        uniq, want_uniq = bench.make_inputs(eng, scheme, n, 12, n_keys=n)        # every signature under its own key
+        from jubjub_schnorr_amd.tools.small_host_calls import formats_of
+        w_rep, w_uniq = formats_of(eng, bench, scheme, rep)["wire"], formats_of(eng, bench, scheme, uniq)["wire"]
+        torch.cuda.synchronize()
+        before = eng.path_stats()
+        for _ in range(3):
+            st, tally = eng.verify_wire(scheme, *w_rep)
+            assert (st == want_rep.cpu().numpy()).all()
+            st, tally = eng.verify_wire(scheme, *w_uniq)
+            want = want_uniq.cpu().numpy()
+            assert (st == want).all(), np.where(st != want)[0][:8]
+            assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+        after = eng.path_stats()
+        assert after["key_tables_wide"] + after["key_tables_narrow"] == before["key_tables_wide"] + before["key_tables_narrow"] + 3, (before, after)
+        assert after["keys_do_not_repeat"] >= before["keys_do_not_repeat"] + 2, (before, after)      # the last call is counted when its slot is next used
+
+
+def test_first_large_call_does_not_stall_small_calls_of_another_thread():
+    """jjs_reserve pre-sizes the engine; no call waits for the device to grow a buffer.  In a fresh process: a thread verifies
+    64 signatures per blocking call in a loop while the main thread issues the FIRST 2^20-item resident call, then a second
+    one.  The slowest small call beside the first large call is no slower than the slowest beside the second one plus one
+    small-call latency -- the first call did not stop the world to allocate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(*flags):
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "reserve_child.py"), *flags], capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    rec = child("--reserve")
+    print(rec)
+    assert rec["bit_exact"] is True
+    assert rec["allocated_by_first_call_bytes"] == 0, rec            # everything the call needed had been reserved
+    assert rec["max_small_ms_beside_first"] <= rec["max_small_ms_beside_second"] + max(rec["median_small_ms_alone"], 0.3) + 0.5, rec
+    # the control: without the reservation the same first call allocates inside the call (and still waits for nobody)
+    ctl = child()
+    print(ctl)
+    assert ctl["bit_exact"] is True and ctl["allocated_by_first_call_bytes"] > 1 << 20 and ctl["allocated_by_second_call_bytes"] == 0, ctl
+
+
+def test_trim_returns_retired_buffers_and_key_pools(eng):
+    import bench
+    import torch
+    arrays, expect = bench.make_inputs(eng, "single", 1 << 17, 5)
+    st, _ = eng.verify("single", *[arrays[k] for k in ARG_ORDER["single"]])
+    torch.cuda.synchronize()
+    assert torch.equal(st, expect)
+    before = eng.memory_stats()
+    assert before["key_pools"] > 0
+    eng.trim()
+    after = eng.memory_stats()
+    assert after["key_pools"] == 0 and after["retired"] == 0
+    st, _ = eng.verify("single", *[arrays[k] for k in ARG_ORDER["single"]])       # the pool comes back
+    torch.cuda.synchronize()
+    assert torch.equal(st, expect) and eng.memory_stats()["key_pools"] >= before["key_pools"] // 4
