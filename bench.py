@@ -513,6 +513,108 @@ def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with
     return rec, ok
 
 
+MSIG_BYTES_PER_SHARE = 32 + 3 * 64 + 1             # z, PK, R, S in; share status out
+MSIG_BYTES_PER_TRANSCRIPT = 32 + 64 + 32 + 64 + 1  # m in; aggregate key, u, R, transcript status out
+
+
+def run_multisig(eng, args, with_cpu: bool, log2_shares: int = 17):
+    """Secondary record (never `value`): batch `verify_share` / `combine` / `aggregate_pk` (reference src/multisig.rs:154-156,
+    284-387) on VALID transcripts -- tests/golden/multisig_valid_transcripts.npz (32 transcripts of 8 participants signed as
+    sign_round_2 does, made by tests/golden/make_multisig_fixture.py), tiled to 2^17 shares, one share in 16 then spoilt
+    (z + 1: InvalidMultisigShare for that share, no signature for its transcript).  Every output is checked against what the
+    fixture holds.  cpu_baseline: the reference's algorithm (oracle/jjs_oracle.c jjo_multisig_combine) on a bounded sample."""
+    import numpy as np
+    import torch
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "multisig_valid_transcripts.npz"))
+    per, base_t = int(fx["participants"]), len(fx["m"])
+    base_n = per * base_t
+    reps = max(1, (1 << log2_shares) // base_n)
+    n, B = reps * base_n, reps * base_t
+    tile = lambda a: np.tile(a, (reps, 1))                 # noqa: E731
+    z = tile(fx["z"]).copy()
+    rng = np.random.default_rng(SEED)
+    spoil = np.zeros(n, bool)
+    spoil[rng.choice(n, n // 16, replace=False)] = True
+    z[spoil, 0] ^= 1                                       # another scalar < r (the top byte is untouched): the share no longer verifies
+    want_share = np.where(spoil, 4, 0).astype(np.uint8)
+    bad_t = spoil.reshape(B, per).any(1)
+    want_t = np.where(bad_t, 4, 0).astype(np.uint8)
+    want_u, want_R, want_agg = tile(fx["sig_u"]).copy(), tile(fx["sig_R"]).copy(), tile(fx["agg_pk"])
+    # u = sum z_i changes with a spoilt share, but such a transcript returns no signature at all
+    want_u[bad_t] = 0; want_R[bad_t] = 0
+    offs = (np.arange(B + 1, dtype=np.int64) * per).astype(np.uint32)
+    host = {"z": z, "PK": tile(fx["PK"]), "R": tile(fx["R"]), "S": tile(fx["S"]), "m": tile(fx["m"])}
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in host.items()}
+
+    def call():
+        return eng.multisig_combine(dev["z"], dev["PK"], dev["R"], dev["S"], dev["m"], offs)
+    for _ in range(args.warmup):
+        out = call()
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = call(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    st, agg, su, sr, ts = (t.cpu().numpy() for t in out)
+    ok = bool((st == want_share).all() and (ts == want_t).all() and (agg == want_agg).all() and (su == want_u).all() and (sr == want_R).all())
+    algo = MSIG_BYTES_PER_SHARE * n + MSIG_BYTES_PER_TRANSCRIPT * B
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    rec = {"value": n * args.steps / elapsed, "unit": "shares/s", "ms_per_step": elapsed / args.steps * 1e3, "shares": n, "transcripts": B,
+           "participants_per_transcript": per, "invalid_shares": int(spoil.sum()), "transcripts_without_signature": int(bad_t.sum()),
+           "bit_exact": {"share_status": bool((st == want_share).all()), "transcript_status": bool((ts == want_t).all()),
+                         "aggregate_keys": bool((agg == want_agg).all()), "signatures": bool((su == want_u).all() and (sr == want_R).all())},
+           "workload": "verify_share + combine + aggregate_pk over %d transcripts of %d participants (fixture tiled %d x), resident in HBM" % (B, per, reps),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": None, "algorithmic_bytes_per_launch": algo, "kernel": "msig_kernel, seven passes", "kernel_ms": kernel_ms}}
+    # a long transcript: the call's time is that of its longest sponge chain (timing only: random shares, statuses not
+    # compared here; tests/test_gpu_parity.py checks 257 and 1 000 participants against the oracle)
+    long_ms = {}
+    for parts in (256, 1000):
+        k = {"z": dev["z"][:parts], "PK": dev["PK"][:parts], "R": dev["R"][:parts], "S": dev["S"][:parts], "m": dev["m"][:1]}
+        o1 = np.array([0, parts], np.uint32)
+        eng.multisig_combine(k["z"], k["PK"], k["R"], k["S"], k["m"], o1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.multisig_combine(k["z"], k["PK"], k["R"], k["S"], k["m"], o1)
+        torch.cuda.synchronize()
+        long_ms[str(parts)] = round((time.perf_counter() - t1) * 1e3, 2)
+    rec["one_transcript_ms"] = long_ms
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import jjs_oracle_c as oc
+        try:
+            oc.build(native=True)
+            native = True
+        except Exception:
+            native = False
+        info = host_info()
+        probe_t = 64
+
+        def probe_rate(t):
+            t1 = time.perf_counter()
+            oc.multisig_combine(*[host[k][: probe_t * per] for k in ("z", "PK", "R", "S")], host["m"][:probe_t], offs[: probe_t + 1], threads=t, native=native)
+            return probe_t * per / (time.perf_counter() - t1)
+        threads, rate, probe_rates = pick_threads(probe_rate, info, oc.max_threads(native))
+        sample_t = int(min(B, max(probe_t, rate * 8.0 / per)))
+        t1 = time.perf_counter()
+        c_share, c_ts, c_agg, c_u, c_R = oc.multisig_combine(*[host[k][: sample_t * per] for k in ("z", "PK", "R", "S")], host["m"][:sample_t],
+                                                              offs[: sample_t + 1], threads=threads, native=native)
+        dt = time.perf_counter() - t1
+        same = bool((c_share == st[: sample_t * per]).all() and (c_ts == ts[:sample_t]).all() and (c_agg == agg[:sample_t]).all() and
+                    (c_u == su[:sample_t]).all() and (c_R == sr[:sample_t]).all())
+        ok = ok and same
+        rec["cpu_baseline"] = {"value": sample_t * per / dt, "unit": "shares/s", "cores": threads, "kind": "port", "cpu_model": info["cpu_model"],
+                               "sample": "first %d transcripts (%d shares) of the same batch, oracle/jjs_oracle.c jjo_multisig_combine (the reference's "
+                                         "algorithm, src/multisig.rs:326-387, 393-500), %d threads, %.1f s" % (sample_t, sample_t * per, threads, dt),
+                               "outputs_equal_gpu": same}
+    return rec, ok
+
+
 def write_full_record(full: dict):
     """The whole record (every scheme's roofline, clocks, notes, per-call times) goes to a file; stdout carries the compact
     line, which fits the tail a driver keeps."""
@@ -601,9 +703,17 @@ def compact_line(full: dict, path) -> dict:
         line["unique_keys"] = short(full["unique_keys"])
     if "single_2p21" in full:
         line["single_2p21"] = short(full["single_2p21"])
-    for k in ("small_host_calls", "multisig"):
-        if k in full:
-            line[k] = full[k]
+    if "small_host_calls" in full:
+        line["small_host_calls"] = full["small_host_calls"]
+    if "multisig" in full:
+        mrec = full["multisig"]
+        line["multisig"] = {"value": _round(mrec["value"], 0), "unit": mrec["unit"], "ms_per_step": _round(mrec["ms_per_step"]), "shares": mrec["shares"],
+                            "participants_per_transcript": mrec["participants_per_transcript"], "invalid_shares": mrec["invalid_shares"],
+                            "bit_exact": all(mrec["bit_exact"].values()), "hbm_frac": _round(mrec["roofline"]["frac"], 5),
+                            "one_transcript_ms": mrec["one_transcript_ms"]}
+        if "cpu_baseline" in mrec:
+            line["multisig"]["cpu_baseline"] = {"value": _round(mrec["cpu_baseline"]["value"], 0), "cores": mrec["cpu_baseline"]["cores"],
+                                                "outputs_equal_gpu": mrec["cpu_baseline"]["outputs_equal_gpu"]}
     line["full_record"] = path
     return line
 
@@ -657,8 +767,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scheme", default="all", choices=["all", "single", "double", "vargen"],
-                    help="all (default): headline = single, plus double and vargen in `schemes`")
+    ap.add_argument("--scheme", default="all", choices=["all", "single", "double", "vargen", "multisig"],
+                    help="all (default): headline = single, plus double and vargen in `schemes` (and the multisig batch as a secondary "
+                         "record); multisig: only the multisignature batch, SURVEY.md 8(f-1), as a line of its own")
     ap.add_argument("--log2-items-per-gpu", type=int, default=None,
                     help="override the BASELINE sizes (2^20 per GPU; 2^21 for single at --gpus 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -717,6 +828,21 @@ def main():
         _ffi.select_library(args.lib)
     import jubjub_schnorr_amd as jjs
     eng = jjs.engine()
+    if args.scheme == "multisig":
+        if world != 1:
+            raise SystemExit("--scheme multisig is a one-GPU record")
+        rec, ok = run_multisig(eng, args, not args.no_cpu_baseline)
+        line = {"metric": "multisig shares verified/sec (verify_share + combine)", "value": rec["value"], "unit": rec["unit"], "n_gpus": 1,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u32 limbs (29-bit), u64 accumulators", "data": "fixture (valid transcripts), tiled",
+                "config": {"workload": rec["workload"]}, "bit_exact": rec["bit_exact"], "roofline": rec["roofline"],
+                "one_transcript_ms": rec["one_transcript_ms"], "invalid_shares": rec["invalid_shares"]}
+        if "cpu_baseline" in rec:
+            line["cpu_baseline"] = rec["cpu_baseline"]
+        print(json.dumps(line), flush=True)
+        if not ok:
+            raise SystemExit("bit-exact check failed")
+        return
     schemes = ["single", "double", "vargen"] if args.scheme == "all" else [args.scheme]
     with_cpu = (not args.no_cpu_baseline) and world == 1
     records, all_ok = {}, True
@@ -744,6 +870,10 @@ def main():
             all_ok = all_ok and ok
             torch.cuda.empty_cache()
 
+    if rank == 0 and world == 1 and args.scheme == "all" and not (args.wire or args.ext):
+        # the multisignature batch under the same measurement contract (secondary record)
+        extras["multisig"], ok = run_multisig(eng, args, with_cpu)
+        all_ok = all_ok and ok
     if rank == 0 and world == 1 and args.scheme == "all" and not (args.wire or args.ext or args.no_host_buffers):
         # the reference's own call pattern: few signatures per blocking call, several host threads (secondary record)
         from jubjub_schnorr_amd.tools import small_host_calls

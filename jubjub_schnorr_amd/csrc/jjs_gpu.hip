@@ -48,7 +48,6 @@
 #include "key_tables.h"
 #include "sign_core.h"
 #include "multisig_core.h"
-#include "safe_tag.h"
 #include "jjs_sponge_tags_long.inc"
 
 using namespace jjs;
@@ -1008,15 +1007,13 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     if (!offsets_host || offsets_host[0] != 0) return fail(JJS_ERR_ARG, "offsets must start at 0");
     // A transcript takes any number of participants: none is the reference's InvalidMultisigTranscript (status 5 for that
     // transcript, the others are not affected), and beyond the JJS_MSIG_MAX_PARTICIPANTS the tag table covers the two
-    // SAFE tags of the transcript are computed here (csrc/safe_tag.h) and travel with the call.
-    bool any_long = false;
+    // SAFE tags of the transcript are computed by the first pass on the device (csrc/safe_tag.h).
     for (size_t t = 0; t < n_transcripts; ++t) {
         if (offsets_host[t + 1] < offsets_host[t]) return fail(JJS_ERR_ARG, "transcript %zu: offsets must not decrease", t);
         const uint64_t cnt = offsets_host[t + 1] - offsets_host[t];
         if (cnt > JJS_MSIG_PARTICIPANTS_LIMIT)
             return fail(JJS_ERR_ARG, "transcript %zu: %llu participants (the hash transcripts are indexed with 32 bits: at most %u)", t,
                         (unsigned long long)cnt, (unsigned)JJS_MSIG_PARTICIPANTS_LIMIT);
-        any_long = any_long || cnt > JJS_MSIG_MAX_PARTICIPANTS;
     }
     const size_t n = offsets_host[n_transcripts];
     if ((n && !all_ok(z, PK, R, S)) || !all_ok(m, agg_pk, sig_u, sig_R) || (n && !share_status)) return fail(JJS_ERR_ARG, "null or misaligned pointer");
@@ -1048,23 +1045,11 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
     P.offsets = d_off;
     P.tags = g->tags_long; P.comb_g = g->comb_g; P.lane_ws = g->slots[0].workspace;
     P.max_table_participants = JJS_MSIG_MAX_PARTICIPANTS;
-    P.long_tags = any_long ? d_long : nullptr;
+    P.long_tags = d_long;
     big_slot();
     if (int rc = begin_shared(s)) return rc;
-    std::vector<uint32_t> long_tags;            // outlives the (pageable, hence staged) copy below
     auto queue = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        if (any_long) {
-            long_tags.assign(n_transcripts * 18, 0u);
-            for (size_t t = 0; t < n_transcripts; ++t) {
-                const uint32_t cnt = offsets_host[t + 1] - offsets_host[t];
-                if (cnt <= JJS_MSIG_MAX_PARTICIPANTS) continue;
-                safe_tag_limbs(2u + 2u * cnt, JJS_Q_WORDS, &long_tags[18 * t]);
-                safe_tag_limbs(3u + 4u * cnt, JJS_Q_WORDS, &long_tags[18 * t + 9]);
-            }
-            HIP_TRY(hipMemcpyAsync(d_long, long_tags.data(), long_tags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));       // rare path (a transcript of more than 256 participants): keep it simple
-        }
         for (int pass = 0; pass < 7; ++pass) {
             const size_t count = (pass == 0 || pass == 2 || pass == 4 || pass == 6) ? n_transcripts : n;
             hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g->grid_msig, count)), dim3(BLOCK), 0, s, P, pass);

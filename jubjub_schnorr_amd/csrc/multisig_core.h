@@ -11,6 +11,7 @@
 // transcript; the hash chains (2 + 2n and 3 + 4n inputs) run inside a lane.
 #pragma once
 #include "sign_core.h"
+#include "safe_tag.h"
 
 namespace jjs {
 
@@ -27,8 +28,8 @@ struct msig_params {
     uint8_t* transcript_status;          // B bytes: 0 = combine returns the signature; else the first share's failure
     uint32_t *tr_of, *d_words, *dpk, *e_pt, *a_words, *c_words;   // scratch: N, N x 8, N x 36, N x 36, B x 8, B x 8
     const uint32_t* tags;                // SAFE tags [JJS_LONG_TAGS][9]: transcripts of up to JJS_MSIG_MAX_PARTICIPANTS participants
-    const uint32_t* long_tags;           // [B][2][9], or nullptr: the two tags of every longer transcript, computed by the host
-                                         // for this call (csrc/safe_tag.h); rows of the other transcripts are not read
+    uint32_t* long_tags;                 // scratch [B][2][9]: the two tags of every longer transcript, computed by pass 0
+                                         // (csrc/safe_tag.h); rows of the other transcripts are neither written nor read
     uint32_t max_table_participants, pad2_;
     const uint32_t* comb_g;
     uint32_t* lane_ws;                   // WS_WORDS_PER_LANE per resident lane
@@ -55,9 +56,18 @@ JJS_HD ext_pt load_ext(const uint32_t* src) {
 JJS_HD words8 load_w8(const uint32_t* p) { words8 w; for (int i = 0; i < 8; ++i) w.w[i] = p[i]; return w; }
 JJS_HD void store_w8(uint32_t* p, const words8& w) { for (int i = 0; i < 8; ++i) p[i] = w.w[i]; }
 
-// pass 0 (lane per transcript): participant -> transcript map
+// pass 0 (lane per transcript): participant -> transcript map; the SAFE tags of a transcript beyond the generated table
 JJS_HD void msig_map_item(const msig_params& P, uint32_t t) {
     for (uint32_t i = P.offsets[t]; i < P.offsets[t + 1]; ++i) P.tr_of[i] = t;
+    const uint32_t cnt = P.offsets[t + 1] - P.offsets[t];
+    if (cnt > P.max_table_participants) {
+        uint32_t q[8], tag[9];
+        for (int k = 0; k < 8; ++k) q[k] = JJS_Q_WORDS[k];
+        safe_tag_limbs(2u + 2u * cnt, q, tag);
+        for (int k = 0; k < 9; ++k) P.long_tags[18 * (size_t)t + k] = tag[k];
+        safe_tag_limbs(3u + 4u * cnt, q, tag);
+        for (int k = 0; k < 9; ++k) P.long_tags[18 * (size_t)t + 9 + k] = tag[k];
+    }
 }
 // pass 1 (lane per participant): d_i = H(pk_i, pk_lo .. pk_hi), D_i = d_i * PK_i
 JJS_HD void msig_delin_item(const msig_params& P, uint64_t i, uint32_t* ws) {

@@ -46,6 +46,7 @@ def load(native: bool = False):
         "jjo_scalar_mul": [P, P, Z, P, I],
         "jjo_point_flags": [P, Z, P, I],
         "jjo_point_add": [P, P, Z, P],
+        "jjo_multisig_combine": [P, P, P, P, P, P, Z, P, P, P, P, P, P, I],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -178,3 +179,25 @@ def point_add(P, Q):
     out = np.empty_like(P)
     assert load().jjo_point_add(_p(P), _p(Q), len(P), _p(out)) == 0
     return out
+
+
+def multisig_combine(z, PK, R, S, m, offsets, threads=0, native=False):
+    """combine / verify_share / aggregate_pk over many transcripts with the reference's algorithm (jjo_multisig_combine):
+    returns (share_status (N,), transcript_status (B,), agg_pk (B, 64), sig_u (B, 32), sig_R (B, 64))."""
+    import jjs_oracle as o
+    z, PK, R, S, m = _c(z, 32), _c(PK, 64), _c(R, 64), _c(S, 64), _c(m, 32)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint32)
+    B, N = len(offs) - 1, len(z)
+    tags = np.zeros((max(B, 1), 2, 32), np.uint8)
+    cache = {}
+    for t in range(B):
+        n = int(offs[t + 1]) - int(offs[t])
+        if n not in cache:
+            cache[n] = [np.frombuffer(o.sponge_tag(k).to_bytes(32, "little"), np.uint8) for k in (2 + 2 * n, 3 + 4 * n)]
+        tags[t, 0], tags[t, 1] = cache[n]
+    share = np.zeros(max(N, 1), np.uint8)[:N]
+    tst = np.zeros(max(B, 1), np.uint8)[:B]
+    agg, su, sr = np.zeros((max(B, 1), 64), np.uint8)[:B], np.zeros((max(B, 1), 32), np.uint8)[:B], np.zeros((max(B, 1), 64), np.uint8)[:B]
+    rc = load(native).jjo_multisig_combine(_p(z), _p(PK), _p(R), _p(S), _p(m), offs.ctypes.data_as(ctypes.c_void_p), B, _p(tags), _p(share), _p(tst), _p(agg), _p(su), _p(sr), threads)
+    assert rc == 0
+    return share, tst, agg, su, sr

@@ -329,16 +329,10 @@ int jjs_host_multisig(const uint8_t* z, const uint8_t* PK, const uint8_t* R, con
     P.share_status = status; P.agg_pk = agg_pk; P.sig_u = sig_u; P.sig_R = sig_R; P.transcript_status = transcript_status;
     P.tr_of = tr.data(); P.d_words = d.data(); P.dpk = dpk.data(); P.e_pt = ept.data(); P.a_words = a.data(); P.c_words = c.data();
     P.tags = &JJS_SPONGE_TAG_LONG[0][0]; P.comb_g = g_comb_g.data();
-    // transcripts beyond the tag table: the two tags per transcript, as jjs_multisig_combine_dev computes them
-    std::vector<uint32_t> long_tags(18 * B, 0u);
+    // transcripts beyond the tag table: pass 0 computes the two tags per transcript (csrc/safe_tag.h), as on the device
+    std::vector<uint32_t> long_tags(18 * B + 18, 0u);
     P.max_table_participants = JJS_MSIG_MAX_PARTICIPANTS;
-    for (size_t t = 0; t < B; ++t) {
-        const uint32_t cnt = offsets[t + 1] - offsets[t];
-        if (cnt <= JJS_MSIG_MAX_PARTICIPANTS) continue;
-        safe_tag_limbs(2u + 2u * cnt, JJS_Q_WORDS, &long_tags[18 * t]);
-        safe_tag_limbs(3u + 4u * cnt, JJS_Q_WORDS, &long_tags[18 * t + 9]);
-        P.long_tags = long_tags.data();
-    }
+    P.long_tags = long_tags.data();
     uint32_t* w = (uint32_t*)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
     for (size_t t = 0; t < B; ++t) msig_map_item(P, (uint32_t)t);
     for (size_t i = 0; i < n; ++i) msig_delin_item(P, i, w);

@@ -165,7 +165,9 @@ def test_first_large_call_does_not_stall_small_calls_of_another_thread():
     print(rec)
     assert rec["bit_exact"] is True
     assert rec["allocated_by_first_call_bytes"] == 0, rec            # everything the call needed had been reserved
-    assert rec["max_small_ms_beside_first"] <= rec["max_small_ms_beside_second"] + max(rec["median_small_ms_alone"], 0.3) + 0.5, rec
+    # "one small-call latency" is that of a small call beside a 2^20 batch (several ms: the chip is full), i.e. what the
+    # loop sees beside the SECOND large call, which allocates nothing by construction
+    assert rec["max_small_ms_beside_first"] <= 2 * rec["max_small_ms_beside_second"] + 0.5, rec
     # the control: without the reservation the same first call allocates inside the call (and still waits for nobody)
     ctl = child()
     print(ctl)

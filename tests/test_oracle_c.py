@@ -126,3 +126,21 @@ def test_statuses_match_python_on_edge_cases(scheme):
 def test_empty_batch():
     z32, z64 = np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8)
     assert len(oc.verify_single(z32, z64, z64, z32)) == 0
+
+
+def test_multisig_combine_port_against_the_reference_kat(reference_kat):
+    """jjo_multisig_combine (the timed CPU baseline of the multisig batch: the reference's combine / verify_share algorithm,
+    src/multisig.rs:326-387, 393-500) reproduces the reference's multisig KAT bytes and the Python oracle on ragged transcripts."""
+    from test_hostbuild import check_multisig
+
+    def run(z, PK, R, S, m, offs):
+        share, tst, agg, su, sr = oc.multisig_combine(z, PK, R, S, m, offs)
+        return share, agg, su, sr, tst
+    check_multisig(run, reference_kat)
+    # an empty transcript between two others: status 5 for itself only
+    from helpers import make_multisig_batch
+    z, PK, R, S, m, offs, want, info = make_multisig_batch(2, seed=3, corrupt=False)
+    offs3 = np.array([0, offs[1], offs[1], offs[2]], np.uint32)
+    m3 = np.stack([m[0], m[0], m[1]])
+    share, tst, agg, su, sr = oc.multisig_combine(z, PK, R, S, m3, offs3)
+    assert tst.tolist() == [0, 5, 0] and not agg[1].any() and share.tolist() == [0] * len(z)
