@@ -387,8 +387,10 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         if (is != cs) HIP_TRY(hipStreamWaitEvent(cs, g->chunk_done[i], 0));
         if (i == last_key_piece && J.try_keys) {
             // every key column is on the device (and converted): the key kernels of the whole block, once
+            // (key columns are converted only when they are extended points; else their arrival is all the key kernels wait
+            // for -- chunk_done[j] lies behind whatever else its compute stream was given before, i.e. behind unrelated hashes)
             for (size_t j = 0; j <= i; ++j)
-                if (b.pieces[j].cols & COLS_KEYS) HIP_TRY(hipStreamWaitEvent(sl->key_stream, g->chunk_done[j], 0));
+                if (b.pieces[j].cols & COLS_KEYS) HIP_TRY(hipStreamWaitEvent(sl->key_stream, J.C.ext ? g->chunk_done[j] : g->chunk_up[j], 0));
             if (int rc = job_keys(J)) return rc;
         }
         if (!waiting.empty() && !hashes_blocked(i)) {

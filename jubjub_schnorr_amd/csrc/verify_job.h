@@ -273,6 +273,10 @@ int launch_normalize(normalize_params N, uint64_t first, uint64_t count, uint64_
     const size_t by_share = (count + (size_t)BLOCK * 32 - 1) / ((size_t)BLOCK * 32);
     if (count == n_call) {
         // a whole call: ~8 items per lane at BASELINE sizes (one inversion amortised over them), one item per lane for small calls
+        // (a resident call normalises everything ahead of its hashes: 0.25 ms at 2^20 items, 2.7 % of the batch's instructions.
+        // Hiding it beside the hashes does not pay -- the chip is bound by instruction issue, so the work costs what it costs
+        // wherever it runs: the leading 2^16 items normalised first and the rest on a priority stream beside their hashes
+        // measured 1-3 % SLOWER, 16 items per lane instead of 8 the same within noise: profiles/r04_ext_pipeline_ab*.txt)
         if (blocks > 512) blocks = 512;
     } else {
         // a range of a host-buffer call: ~8 items per lane from 2^18 items on (an inversion is 12 items' worth of products)

@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [HERE, os.path.join(HERE, "..", "oracle"), os.path.join(HERE, "..")]
 
 
-def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
+def run_soak(log2n=20, schemes=("single", "double", "vargen")) -> dict:
+    """log2n: one size for every scheme, or a dict {scheme: log2 of its item count}."""
     import torch
 
     import bench
@@ -29,7 +30,7 @@ def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
     except Exception:
         native = False
     fns = {"single": oc.verify_single, "double": oc.verify_double, "vargen": oc.verify_vargen}
-    n = 1 << log2n
+    sizes = {s: 1 << (log2n[s] if isinstance(log2n, dict) else log2n) for s in schemes}
     eng = jjs.engine()
     t8 = torsion_generator()
     tors = pt_arr([o.mul(t8, k) for k in range(1, 8)])
@@ -44,9 +45,10 @@ def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
         return 4096 / (time.time() - t0)
 
     threads, _, _ = bench.pick_threads(probe_rate, info, oc.max_threads(native))
-    report = {"items_per_scheme": n, "csrc_sha256": bench.csrc_hash(), "oracle": "oracle/jjs_oracle.c", "host": info,
+    report = {"items_per_scheme": sizes, "csrc_sha256": bench.csrc_hash(), "oracle": "oracle/jjs_oracle.c", "host": info,
               "oracle_threads": threads, "schemes": {}}
     for scheme in schemes:
+        n = sizes[scheme]
         arrays, _ = bench.make_inputs(eng, scheme, n, 0)
         host = {k: v.cpu().numpy().copy() for k, v in arrays.items()}
         # small-order components on 1/64 of the items, spread over the points the bench mix leaves clean
@@ -81,8 +83,11 @@ def run_soak(log2n: int = 20, schemes=("single", "double", "vargen")) -> dict:
         st_h, tally_h = eng.verify(scheme, *[host[k] for k in names])
         ext = [ext_on_device(eng, host[k], seed=5) if host[k].shape[1] == 64 else host[k] for k in names]
         st_e, tally_e = eng.verify_ext(scheme, *ext)
+        st_ed, tally_ed = eng.verify_ext(scheme, *[torch.from_numpy(a).cuda() for a in ext])      # resident: normalised beside the hashes
+        bad_ext_dev = int((st_ed.cpu().numpy() != want).sum()) + (0 if tally_ed.cpu().numpy().tolist() == hist else 1)
         st_hw, tally_hw = eng.verify_wire(scheme, sig.contiguous().cpu().numpy(), pk.contiguous().cpu().numpy(), host["m"])
-        bad_host = {"affine": int((st_h != want).sum()), "ext": int((st_e != want).sum()), "wire": int((st_hw != want).sum())}
+        bad_host = {"affine": int((st_h != want).sum()), "ext": int((st_e != want).sum()), "wire": int((st_hw != want).sum()),
+                    "ext_resident": bad_ext_dev}
         tallies_host = [t.tolist() for t in (tally_h, tally_e, tally_hw)]
         print(f"{scheme}: host-buffer entry points, mismatches {bad_host}", flush=True)
         del ext

@@ -624,6 +624,19 @@ def test_key_kernel_scheduling_boundaries(eng, n):
             st, tally = eng.verify(scheme, *[arrays[k] for k in ARG_ORDER[scheme]])
             assert torch.equal(st, expect), (scheme, n)
             assert host(tally).tolist() == [int((expect == k).sum()) for k in range(4)]
+        if n >= 1 << 18:
+            # the same batches as extended points (normalised on the device ahead of the key kernels and the hashes)
+            zgen = torch.Generator(device="cpu").manual_seed(n)
+
+            def to_ext(pts):
+                z = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=zgen)
+                z[:, 31] &= 0x3F; z[:, 0] |= 1
+                z = z.cuda()
+                return torch.cat([eng.debug_fq_mul(pts[:, :32].contiguous(), z), eng.debug_fq_mul(pts[:, 32:].contiguous(), z), z], 1).contiguous()
+            ext = [to_ext(arrays[k]) if arrays[k].shape[1] == 64 else arrays[k] for k in ARG_ORDER[scheme]]
+            st, tally = eng.verify_ext(scheme, *ext)
+            assert torch.equal(st, expect), (scheme, n, "ext")
+            assert host(tally).tolist() == [int((expect == k).sum()) for k in range(4)]
 
 
 @pytest.mark.parametrize("n_keys", [1, 2, 1024, 1025, 8191, 8192, 8193, 1 << 17])

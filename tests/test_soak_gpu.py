@@ -1,4 +1,5 @@
-"""Parity by the oracle, not by construction, at scale: every status byte of 2^19 items per scheme against the C
+"""Parity by the oracle, not by construction, at scale: every status byte of 2^20 single, 2^19 double and 2^19
+var-generator signatures against the C
 restatement of the reference's algorithm on all host cores (~2 min of 16 threads): the device entry points (affine and
 wire) and the blocking host-buffer entry points (affine, extended, wire).
 JJS_SOAK_LOG2N overrides the size: the committed records profiles/r03_soak.json (round 2: r02z_soak.json) are runs with
@@ -15,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(800)
 def test_soak_every_status_against_the_oracle():
     import soak_gpu
-    log2n = int(os.environ.get("JJS_SOAK_LOG2N", "19"))
+    # BASELINE.json configs[1] at its full size (2^20 single signatures); configs[2] and [4] at half of theirs
+    log2n = int(os.environ["JJS_SOAK_LOG2N"]) if "JJS_SOAK_LOG2N" in os.environ else {"single": 20, "double": 19, "vargen": 19}
     rep = soak_gpu.run_soak(log2n)
     soak_gpu.write_report(rep, os.path.join(ROOT, "gpurun_out", "soak.json"))
     for scheme, r in rep["schemes"].items():
