@@ -47,9 +47,9 @@ ARG_ORDER = {"single": ["u", "R", "PK", "m"], "double": ["u", "R", "Rp", "PK", "
              "vargen": ["u", "R", "PK", "Gen", "m"]}
 
 
-def make_inputs(eng, scheme: str, n: int, rank: int, n_keys: int = N_KEYS):
+def make_inputs(eng, scheme: str, n: int, rank: int, n_keys: int = N_KEYS, mix: bool = True):
     """Returns (dict of CUDA uint8 tensors, expected status tensor).  n_keys: distinct key pairs (SURVEY.md 8d: 4 096;
-    n_keys = n gives every signature its own key)."""
+    n_keys = n gives every signature its own key).  mix=False: every signature valid (nothing spoilt)."""
     import torch
     gen = torch.Generator(device="cpu").manual_seed(SEED + 7919 * rank)
     N_KEYS = max(2, min(int(n_keys), n))         # noqa: N806  (shadows the module default on purpose)
@@ -76,6 +76,8 @@ def make_inputs(eng, scheme: str, n: int, rank: int, n_keys: int = N_KEYS):
         u, R, PK, Gen = eng.sign(scheme, sk, rnd, m, gen_scalar=g)
         a = {"u": u, "R": R, "PK": PK, "Gen": Gen, "m": m}
     torch.cuda.synchronize()
+    if not mix:
+        return {k: v.contiguous() for k, v in a.items()}, torch.zeros(n, dtype=torch.uint8, device="cuda")
 
     sel = torch.randint(0, 256, (n,), generator=gen).cuda()
     idx = torch.arange(n, device="cuda")
@@ -305,7 +307,9 @@ def alu_roofline(pmc: dict, kernel_ms: float, clocks) -> dict:
            "power_w_median": (clocks or {}).get("power_w_median"),
            "cycles_per_wave_instr": cycles, "floor_cycles_per_wave_instr": floor, "int64_class_share": share if i64 else None,
            "valu_wave_instr_per_launch": insts, "valu_wave_instr_per_64_verifies": insts / (pmc["items"] / 64),
-           "source": pmc.get("source"),
+           "source": pmc.get("source"), "dominant_kernel": pmc.get("dominant_kernel"),
+           # per kernel, from its own PMC counts and its own busy cycles (GRBM_GUI_ACTIVE), dispatches serialised: no clock needed
+           "per_kernel": {k: v.get("alu_frac_alone") for k, v in (pmc.get("per_kernel") or {}).items()} or None,
            "note": "floor = 4 cycles x share of 64-bit multiply-add / shift instructions + 2 cycles x the rest; frac = floor / cycles"}
     emp = microbench_ceiling()
     if emp:
@@ -361,12 +365,12 @@ def workload_name(scheme: str, n: int, world: int) -> str:
     return f"2^{lg} {scheme} signatures per GPU, resident in HBM{exact}(BASELINE.json configs[{cfg}] per GPU)"
 
 
-def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with_cpu: bool, n_keys: int = N_KEYS):
+def run_scheme(eng, scheme: str, n: int, args, dist, rank: int, world: int, with_cpu: bool, n_keys: int = N_KEYS, mix: bool = True):
     """W warm-up steps, then exactly K timed steps between two barrier + synchronize fences; returns the record of
     this scheme (rank 0) and whether every bit-exact check held (every rank)."""
     import torch
     from jubjub_schnorr_amd.sharding import allreduce_tally
-    arrays, expect = make_inputs(eng, scheme, n, rank, n_keys)
+    arrays, expect = make_inputs(eng, scheme, n, rank, n_keys, mix)
     call = [arrays[k] for k in ARG_ORDER[scheme]]
     if args.wire:
         c = {k: eng.compress(v) for k, v in arrays.items() if v.shape[1] == 64}
@@ -644,7 +648,7 @@ def compact_line(full: dict, path) -> dict:
                 "achieved": _round(alu["achieved"], 0), "peak": _round(alu["peak"], 0), "unit": alu["unit"],
                 "cycles_per_wave_instr": _round(alu["cycles_per_wave_instr"]), "floor_cycles_per_wave_instr": _round(alu["floor_cycles_per_wave_instr"]),
                 "valu_wave_instr_per_64_verifies": _round(alu["valu_wave_instr_per_64_verifies"], 0),
-                "per_kernel": alu.get("per_kernel"), "source": alu.get("source")}
+                "dominant_kernel": alu.get("dominant_kernel"), "per_kernel": alu.get("per_kernel"), "source": alu.get("source")}
 
     def host_rates(hb):
         if not hb:
@@ -703,6 +707,8 @@ def compact_line(full: dict, path) -> dict:
         line["unique_keys"] = short(full["unique_keys"])
     if "single_2p21" in full:
         line["single_2p21"] = short(full["single_2p21"])
+    if "single_all_valid" in full:
+        line["single_all_valid"] = short(full["single_all_valid"])
     if "small_host_calls" in full:
         line["small_host_calls"] = full["small_host_calls"]
     if "multisig" in full:
@@ -868,6 +874,12 @@ def main():
             lean = argparse.Namespace(**{**vars(args), "no_two_streams": True, "no_host_buffers": True, "no_clock_sampling": True})
             base_2p21, ok = run_scheme(eng, "single", 1 << 21, lean, dist, rank, world, False)
             all_ok = all_ok and ok
+            torch.cuda.empty_cache()
+            # configs[1] with every signature valid: what a caller whose traffic is honest sees (the mix spends 2-3 % of a
+            # batch on its 1/16 of bad items: their R points' own subgroup tests run as a pass of their own behind the equations)
+            all_valid, ok = run_scheme(eng, "single", 1 << 20, lean, dist, rank, world, False, mix=False)
+            all_ok = all_ok and ok
+            extras["single_all_valid"] = {k: all_valid[k] for k in ("value", "unit", "ms_per_step", "workload", "items_per_gpu", "bit_exact")}
             torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and args.scheme == "all" and not (args.wire or args.ext):

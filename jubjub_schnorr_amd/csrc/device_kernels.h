@@ -160,26 +160,37 @@ __global__ __launch_bounds__(BLOCK, 2) void key_chain_kernel(key_params K) {
     const int w = (int)K.counters[2];
     if (!w) return;
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x, keys = K.n_cols * K.max_keys;
+    // a key found valid joins the list of the keys that get tables (key_table_kernel)
     if (!K.quad_chains) {
         const uint32_t c = t / K.max_keys, id = t % K.max_keys;
-        if (c < K.n_cols && id < K.counters[c]) kt_chain_key(kt_col(K, (int32_t)c), id, w);
+        if (c < K.n_cols && id < K.counters[c]) {
+            const key_column C = kt_col(K, (int32_t)c);
+            if (kt_chain_key(C, id, w)) C.valid_ids[atomicAdd(&K.counters[5 + c], 1u)] = id;
+        }
     } else if (t < 4 * keys) {
         const uint32_t q = t >> 2, c = q / K.max_keys, id = q % K.max_keys;          // the same for the four lanes of a quad
         if (id < K.counters[c]) kt_chain_key_quad(kt_col(K, (int32_t)c), id, w, t & 3u);
     } else if (t < 5 * keys) {
         const uint32_t q = t - 4 * keys, c = q / K.max_keys, id = q % K.max_keys;
-        if (id < K.counters[c]) kt_key_flags(kt_col(K, (int32_t)c), id);
+        if (id < K.counters[c]) {
+            const key_column C = kt_col(K, (int32_t)c);
+            if (kt_key_flags(C, id)) C.valid_ids[atomicAdd(&K.counters[5 + c], 1u)] = id;
+        }
     }
 }
-// the grid covers max_keys x KT_MAX_POSITIONS lanes per column; a batch with wide windows has fewer of both
+// the grid covers max_keys x KT_MAX_POSITIONS lanes per column; a batch with wide windows has fewer of both, and only the
+// keys whose point is valid get tables (kt_finish_item)
 __global__ __launch_bounds__(BLOCK, 2) void key_table_kernel(key_params K) {
     const int w = (int)K.counters[2];
     if (!w) return;
     const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t positions = (uint32_t)kt_positions(w);
     const uint64_t per_col = (uint64_t)K.max_keys * positions;
-    const uint32_t c = (uint32_t)(t / per_col), id = (uint32_t)((t % per_col) / positions), pos = (uint32_t)(t % positions);
-    if (c < K.n_cols && id < K.counters[c]) kt_table_lane(kt_col(K, (int32_t)c), id, pos, w);
+    const uint32_t c = (uint32_t)(t / per_col), j = (uint32_t)((t % per_col) / positions), pos = (uint32_t)(t % positions);
+    if (c < K.n_cols && j < K.counters[5 + c]) {            // the j-th VALID key of the column
+        const key_column C = kt_col(K, (int32_t)c);
+        kt_table_lane(C, C.valid_ids[j], pos, w);
+    }
 }
 // Items grouped by key (column 0): histogram, exclusive scan, scatter.  All three leave at once when the batch does not
 // take the key-table path.
@@ -269,13 +280,13 @@ __global__ __launch_bounds__(BLOCK, 2) void key_verify_kernel(verify_params P, k
     }
 }
 
-// Second pass: the queued items, densely packed over the lanes, P.resolve_lanes adjacent lanes per item
+// Second pass: the queued items, densely packed over the lanes, P.resolve_lanes (resolve_lanes_keyed) adjacent lanes per item
 // (one point each; see verify_item / resolve_point).
 __global__ __launch_bounds__(BLOCK) void resolve_kernel(verify_params P) {
     const uint64_t gtid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
     const uint64_t count = *P.pending_count;
-    const uint32_t L = P.resolve_lanes;
+    const uint32_t L = keyed_mode(P) ? P.resolve_lanes_keyed : P.resolve_lanes;      // a lane per point that still needs its test
     for (uint64_t base = 0; base < count * L; base += total) {
         const uint64_t slot = base + gtid;
         const uint64_t idx = slot / L;

@@ -109,6 +109,7 @@ struct call_slot {
     hipStream_t table_stream = nullptr;   // key_table_kernel runs here, at the lowest priority: see job_keys
     hipEvent_t last_use = nullptr;    // end of the last launch that used this slot
     hipStream_t last_stream = nullptr;// ... and the stream it was issued on
+    bool host_owned = false;          // a large host-buffer call is feeding this slot right now, outside the engine's mutex (run_host)
 };
 #ifndef JJS_SMALL_SLOTS
 #define JJS_SMALL_SLOTS 6
@@ -215,7 +216,9 @@ struct device_state {
     int grid_msig = 0;
     int key_priority = 0;                // stream priority of the slots' key streams
     int table_priority = 0;              // ... and of their table streams (the lowest)
-    uint64_t stats[JJS_PATH_STATS] = {}; // jjs_path_stats: which path the calls on this device took
+    std::atomic<uint64_t> stats[JJS_PATH_STATS] = {};   // jjs_path_stats: which path the calls on this device took
+    std::mutex host_mu;                  // large host-buffer calls: one at a time per device (they share the staging below)
+    std::mutex retired_mu;               // guards `retired`
     hipStream_t copy_stream = nullptr;   // host-buffer calls: uploads and status downloads, beside `stream`
     hipEvent_t side_join = nullptr, ingest_done = nullptr;
     staging_pool* stagers = nullptr;     // host-buffer calls: the threads that copy pageable -> pinned with the caller's
@@ -311,7 +314,11 @@ void pick_slot(size_t n, hipStream_t s) {
         // a big slot is a big arena: calls that follow each other on one stream are ordered anyway and stay in one
         // slot; a call from another stream takes the other one if this one is still busy
         call_slot &a = g->slots[0], &b = g->slots[SECOND_BIG_SLOT];
-        if (a.last_stream == s) sl = &a;
+        // a large host-buffer call feeds its slot outside the engine's mutex: it always takes the second big slot (the first
+        // also serves the signer, the decoder and the multisig kernels), and nobody else takes that one meanwhile
+        if (s == g->stream) sl = &b;
+        else if (b.host_owned) sl = &a;
+        else if (a.last_stream == s) sl = &a;
         else if (b.last_stream == s) sl = &b;
         else sl = hipEventQuery(a.last_use) == hipSuccess ? &a : (hipEventQuery(b.last_use) == hipSuccess ? &b : (g->next_big++ % N_BIG_SLOTS ? &b : &a));
     }
@@ -339,6 +346,7 @@ size_t grown(size_t want) {              // the smallest of 2^k, 1.5 * 2^k that 
 }
 void retire(void* p, bool host, size_t bytes) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(g->retired_mu);
     try {
         g->retired.push_back(retired_buffer{p, host, bytes});
         g->retired_bytes += bytes;
@@ -348,6 +356,7 @@ void retire(void* p, bool host, size_t bytes) {
     }
 }
 void free_retired(device_state& d) {      // the caller has made sure that the device is idle
+    std::lock_guard<std::mutex> lock(d.retired_mu);
     for (retired_buffer& r : d.retired) {
         if (r.host) (void)hipHostFree(r.p); else (void)hipFree(r.p);
     }

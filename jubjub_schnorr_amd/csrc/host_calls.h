@@ -91,6 +91,8 @@ struct host_block {
     int rc = JJS_OK;
     char err[512] = "";
     unsigned long long tally[4] = {0, 0, 0, 0};
+    bool unlocked = false;     // the call runs outside the engine's mutex (one device; see run_host)
+    call_slot* owned = nullptr;// ... and owns this slot until it returns
 };
 
 // The upload order of a block of nl items.  row_keys / row_rest: bytes per item of the two column groups.
@@ -255,7 +257,13 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
     // The call of this block (the builder picks its slot), and with it the upload order: the columns nothing reads before
     // the equations (u) travel last when the call will hash with the head launch of prepare_kernel, which does not touch
     // them -- i.e. when it tries the key tables (and is not a wire call, whose u sits inside the signature column).
-    if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
+    {
+        // the builder picks the call slot (the engine's state): under the engine's mutex when this call does not hold it anyway
+        std::unique_lock<std::mutex> lock(L.mu, std::defer_lock);
+        if (b.unlocked) lock.lock();
+        if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
+        if (b.unlocked && nl > MEDIUM_SLOT_ITEMS) { sl->host_owned = true; b.owned = sl; }
+    }
     bool late = false;
     for (size_t k = 0; k < n_cols; ++k) late = late || cols[k].group == COLS_LATE;
     late = late && !J.C.wire && !small_path_applies(J.C.P) && key_path_applies(J.C.P) && ensure_key_pool(J.C.P) == JJS_OK;
@@ -448,7 +456,10 @@ int reserve_host_block(const host_col* cols, size_t n_cols, size_t nl, int wire_
     return ensure_pinned(HOST_SLOTS * pad256(largest) + pad256(nl) + 256);
 }
 
-int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, int wire_points) {
+// `unlocked`: the caller does NOT hold the engine's mutex (one driven device: the call holds that device's host_mu instead, so
+// that calls of other threads -- resident ones, and host-buffer calls on the lanes -- are queued while this one uploads and waits)
+int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uint64_t tally[4], call_builder build, int wire_points,
+             bool unlocked = false) {
     if (n_cols > 8) return fail(JJS_ERR_ARG, "internal: too many columns");
     for (size_t k = 0; k < n_cols; ++k)
         if (n && !cols[k].p) return fail(JJS_ERR_ARG, "null input pointer");
@@ -479,6 +490,7 @@ int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uin
         plan_pieces(b.plans[0], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, wire_points, false);
         plan_pieces(b.plans[1], b.largest_bytes, b.hi - b.lo, row_keys, row_rest, row_late, wire_points, true);
         b.staging_threads = staging_threads;
+        b.unlocked = unlocked && nd == 1;
     }
     auto work = [&](size_t d) {
         host_block& b = blocks[d];
@@ -492,6 +504,11 @@ int run_host(const host_col* cols, size_t n_cols, size_t n, uint8_t* status, uin
             for (hipStream_t side : targets[d]->side) (void)hipStreamSynchronize(side);
             for (hipStream_t is : targets[d]->ingest) (void)hipStreamSynchronize(is);
             (void)hipStreamSynchronize(targets[d]->copy_stream);
+        }
+        if (b.owned) {
+            std::lock_guard<std::mutex> lock(L.mu);
+            b.owned->host_owned = false;
+            b.owned = nullptr;
         }
     };
     if (nd == 1) {

@@ -331,6 +331,11 @@ int jjs_init(int device_count) {
 }
 
 void jjs_shutdown(void) {
+    {   // a large host-buffer call in progress finishes first (it holds its device's host_mu, not the engine's mutex)
+        std::vector<device_state*> devs;
+        { std::lock_guard<std::mutex> lock(L.mu); devs = L.devs; }
+        for (device_state* d : devs) { std::lock_guard<std::mutex> big(d->host_mu); }
+    }
     std::unique_lock<std::mutex> lock(L.mu);
     // host-buffer calls that hold a lane finish first (they wait for the device outside the mutex)
     L.lane_cv.wait(lock, [] {
@@ -761,10 +766,27 @@ static int host_call(int scheme, int format, const uint8_t* const* ptrs, size_t 
         return JJS_OK;
     }
     if (one_device && n <= LANE_MAX_ITEMS) return lane_call(scheme, format, ptrs, n, status, tally);
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (int rc = check_ready()) return rc;
     host_col cols[8];
     for (size_t k = 0; k < S.n_cols; ++k) cols[k] = host_col{ptrs[k], S.col[k].width, S.col[k].group};
+    if (one_device) {
+        // A large call fills the device by itself: such calls run one at a time per device (host_mu; they share the device's
+        // staging), but outside the engine's mutex, which they take only to pick their slot -- other threads' calls are queued
+        // meanwhile.  (jjs_shutdown and jjs_trim take host_mu, too.)
+        device_state* dev = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(L.mu);
+            if (int rc = check_ready()) return rc;
+            dev = g;
+        }
+        std::lock_guard<std::mutex> big(dev->host_mu);
+        {
+            std::lock_guard<std::mutex> lock(L.mu);
+            if (L.devs.empty() || check_ready() != JJS_OK || g != dev) return fail(JJS_ERR_NOT_INIT, "the engine was shut down during the call");
+        }
+        return no_throw([&] { return run_host(cols, S.n_cols, n, status, tally, S.build, S.wire_points, true); });
+    }
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (int rc = check_ready()) return rc;
     return no_throw([&] { return run_host(cols, S.n_cols, n, status, tally, S.build, S.wire_points); });
 }
 
@@ -914,8 +936,17 @@ int jjs_reserve(int scheme, int format, size_t n_items, int host_buffers) {
 // Waits for the devices to go idle, then frees what growth has retired and every slot's key-table pool (a later call that
 // takes the key tables allocates its pool again, at the size the slot had learnt).
 int jjs_trim(void) {
+    std::vector<device_state*> devs;
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        if (int rc = check_ready()) return rc;
+        devs = L.devs;
+    }
+    std::vector<std::unique_lock<std::mutex>> big;            // no large host-buffer call in progress on any device
+    for (device_state* d : devs) big.emplace_back(d->host_mu);
     std::unique_lock<std::mutex> lock(L.mu);
     if (int rc = check_ready()) return rc;
+    if (devs != L.devs) return fail(JJS_ERR_NOT_INIT, "the engine was re-initialised during the call");
     device_restore restore;
     for (device_state* d : L.devs) {
         HIP_TRY(hipSetDevice(d->device));
@@ -957,7 +988,7 @@ int jjs_path_stats(uint64_t out[JJS_PATH_STATS]) {
     size_t pool = 0;
     for (call_slot& c : g->slots) {
         sl = &c;
-        if (c.key_stream) note_key_feedback();
+        if (c.key_stream && !c.host_owned) note_key_feedback();     // (a slot a large host-buffer call is feeding: counted by that call's successor)
         pool += c.key_pool_bytes;
     }
     for (int i = 0; i < JJS_PATH_STATS; ++i) out[i] = g->stats[i];

@@ -75,6 +75,8 @@ struct key_column {
     uint32_t* key_item;      // [max_keys] representative item of a key
     uint8_t* key_flags;      // [max_keys] KT_KEY_*
     uint8_t* key_undecodable;// [max_keys] wire calls: the key's encoding is not a point (decode.h)
+    uint32_t* valid_ids;     // [max_keys] the ids of the keys whose point is valid, in the order the chain kernel found them (their
+                             // number: key_params::counters[5 + column]): only these get window tables
     uint32_t* bases;         // [keys][positions][36]: 2^(w i) * P in extended coordinates (w = the window width of this batch)
     uint32_t* tables;        // [keys][positions][table words]: {0 .. 2^(w-1)} * base, cached-addend form
 };
@@ -88,7 +90,7 @@ struct key_params {
     key_column col[2];
     uint32_t* counters;      // [c] distinct keys of column c; [2] the decision: 0 = throughput path, else the window width of
                              // the key-table path; [3] a probe sequence overflowed; [4] the keys repeat but their tables do
-                             // not fit the pool (the host grows it for the next call)
+                             // not fit the pool (the host grows it for the next call); [5 + c] valid keys of column c
     uint32_t force_window;   // profiling build only (0 in the product): KT_WINDOW_NARROW = never the wide windows
     uint32_t keep_order;     // profiling build only (0 in the product): the lanes take the items in the caller's order
     uint64_t n;
@@ -109,6 +111,7 @@ JJS_HD key_column kt_col(const key_params& K, int32_t idx) {
     c.hash = z ? a.hash : b.hash; c.hash_mask = z ? a.hash_mask : b.hash_mask; c.key_bytes = z ? a.key_bytes : b.key_bytes;
     c.rep = z ? a.rep : b.rep; c.keyid = z ? a.keyid : b.keyid; c.key_item = z ? a.key_item : b.key_item;
     c.key_flags = z ? a.key_flags : b.key_flags; c.key_undecodable = z ? a.key_undecodable : b.key_undecodable; c.bases = z ? a.bases : b.bases; c.tables = z ? a.tables : b.tables;
+    c.valid_ids = z ? a.valid_ids : b.valid_ids;
     return c;
 }
 
@@ -179,8 +182,8 @@ JJS_HD void kt_unpack_item(const key_column& C, uint64_t item, uint8_t* out, uin
     if (C.key_undecodable[C.keyid[item]]) bad[item] = 1;
 }
 
-// one key: `is_valid` of its point, and the chain of bases
-JJS_HD void kt_chain_key(const key_column& C, uint32_t id, int w) {
+// one key: `is_valid` of its point (returned), and the chain of bases
+JJS_HD bool kt_chain_key(const key_column& C, uint32_t id, int w) {
     const uint64_t item = C.key_item[id];
     const words8 uw = load_words(C.src, item), vw = load_words(C.src, item, 32);
     const bool canonical = words_lt(uw, JJS_Q_WORDS) && words_lt(vw, JJS_Q_WORDS);
@@ -195,6 +198,7 @@ JJS_HD void kt_chain_key(const key_column& C, uint32_t id, int w) {
         for (int j = 0; j < w; ++j) p = ext_double(p, j == w - 1);
         kt_store_ext(kt_base(C, id, pos, w), p);
     }
+    return valid;
 }
 
 #if defined(__HIPCC__)
@@ -255,13 +259,14 @@ __device__ __forceinline__ void kt_chain_key_quad(const key_column& C, uint32_t 
 }
 #endif
 // `is_valid` of one key's point (the other half of kt_chain_key)
-JJS_HD void kt_key_flags(const key_column& C, uint32_t id) {
+JJS_HD bool kt_key_flags(const key_column& C, uint32_t id) {
     const uint64_t item = C.key_item[id];
     const words8 uw = load_words(C.src, item), vw = load_words(C.src, item, 32);
     const bool canonical = words_lt(uw, JJS_Q_WORDS) && words_lt(vw, JJS_Q_WORDS);
     const fe_n pu = fq_from_words(uw), pv = fq_from_words(vw);
     const bool valid = canonical && point_on_curve_not_identity(pu, pv) && is_torsion_free(pu, pv);
     C.key_flags[id] = (uint8_t)((canonical ? 0u : KT_KEY_MALFORMED) | (valid ? KT_KEY_VALID : 0u));
+    return valid;
 }
 
 // table[j] = j * P for j = 0 .. entries-1, P in extended coordinates (the cached-addend entries keep their Z)
@@ -328,7 +333,10 @@ JJS_HD ext_pt kt_add_scalar(ext_pt acc, const key_column& C, uint32_t id, const 
     return acc;
 }
 
-// The equations of one item through the key tables (step 4 above).  r = prepare_item's record in keyed mode:
+// The equations of one item through the key tables (step 4 above).  A key whose point is not valid has no tables (the table
+// kernel builds them for the valid keys only: an invalid key makes every one of its items InvalidPoint whatever the equation
+// says, and SURVEY.md 8(d)'s mix carries ~2 600 such keys beside its 4 096 good ones): its items add whatever the pool
+// holds there and their verdict ignores the sum.  r = prepare_item's record in keyed mode:
 // challenge, malformed (u, m, the R points), valid (every R point on the curve and not the identity).
 JJS_HD uint32_t kt_finish_item(const verify_params& P, const key_params& K, uint64_t item, const prep_record& r) {
     const int w = (int)*P.key_flag;                  // the window width this batch's tables were built with

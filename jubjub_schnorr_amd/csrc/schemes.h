@@ -28,7 +28,7 @@ inline verify_params params_single(const uint8_t* u, const uint8_t* R, const uin
     P.hash_in[2] = coord_src(PK, 0); P.hash_in[3] = coord_src(PK, 32);
     P.hash_in[4] = fe32_src(m);
     P.points[0] = pt_src(PK); P.points[1] = pt_src(R);
-    P.resolve_lanes = 2;
+    P.resolve_lanes = 2; P.resolve_lanes_keyed = 1;      // R and PK; on the key-table path R alone
     P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R), 0, -1};
     P.key_points_mask = 1u;          // points[0] = PK
     P.u = fe32_src(u);
@@ -48,7 +48,7 @@ inline verify_params params_double(const uint8_t* u, const uint8_t* R, const uin
     P.hash_in[7] = coord_src(PKp, 0); P.hash_in[8] = coord_src(PKp, 32);
     P.hash_in[9] = fe32_src(m);
     P.points[0] = pt_src(PK); P.points[1] = pt_src(PKp); P.points[2] = pt_src(R); P.points[3] = pt_src(Rp);
-    P.resolve_lanes = 4;
+    P.resolve_lanes = 4; P.resolve_lanes_keyed = 2;      // R, R', PK, PK'; on the key-table path R and R'
     P.eq[0] = eq_desc{comb_g, fe_src{nullptr, 0, 0}, pt_src(PK), pt_src(R), 0, -1};
     P.eq[1] = eq_desc{comb_gn, fe_src{nullptr, 0, 0}, pt_src(PKp), pt_src(Rp), 1, -1};
     P.key_points_mask = 3u;          // points[0] = PK, points[1] = PK'
@@ -67,7 +67,7 @@ inline verify_params params_vargen(const uint8_t* u, const uint8_t* R, const uin
     P.hash_in[6] = fe32_src(m);
     P.points[0] = pt_src(PK); P.points[1] = pt_src(Gen); P.points[2] = pt_src(R);
     P.own_test_mask = 3u;            // PK and Gen are tested on their own; R rides on the equation
-    P.resolve_lanes = 1;
+    P.resolve_lanes = 1; P.resolve_lanes_keyed = 1;
     P.eq[0] = eq_desc{nullptr, pt_src(Gen), pt_src(PK), pt_src(R), 0, 1};
     P.key_points_mask = 3u;          // points[0] = PK, points[1] = Gen
     P.u = fe32_src(u);

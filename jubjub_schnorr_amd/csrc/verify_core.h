@@ -66,6 +66,7 @@ struct verify_params {
     uint32_t* workspace;             // WS_WORDS_PER_LANE words per resident lane
     uint32_t own_test_mask;          // bit k: points[k] gets its own subgroup test in the first pass
     uint32_t resolve_lanes;          // lanes per queued item in the resolve pass: 1, 2 or 4 >= points left to test
+    uint32_t resolve_lanes_keyed;    // ... on the key-table path, where the keys have been tested per key (only the R points are left)
     uint32_t decoded_points;         // non-zero: every point was produced by decompress_point (on the curve)
     uint32_t key_points_mask;        // bit k: points[k] is a key column of the key-table path (validated once per key)
     const uint32_t* key_flag;        // device word, non-zero when this batch runs the key-table path (key_tables.h), or nullptr

@@ -163,7 +163,8 @@ int carve_keys(const verify_params& P, key_params& K, uint8_t** cleared, size_t*
     const size_t per_col = pad256(slots * 4) + 2 * pad256(P.n * 4);
     const size_t cursor_words = (size_t)K.max_keys + 1 > (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE ? (size_t)K.max_keys + 1 : (size_t)CURSOR_DENSE_FROM * CURSOR_STRIDE;
     const size_t order_bytes = pad256(P.n * 4) + pad256(cursor_words * 4);
-    if (int rc = ensure_key_index(256 + order_bytes + n_cols * per_col)) return rc;
+    const size_t valid_bytes = pad256(((size_t)K.max_keys + 1) * 4);
+    if (int rc = ensure_key_index(256 + order_bytes + n_cols * (per_col + valid_bytes))) return rc;
     uint8_t* p = sl->keys;
     // what every call finds cleared comes first and side by side (one memset, one launch: the dozen small dependent launches at
     // the head of a call are a third of a 2^16-item batch)
@@ -181,6 +182,7 @@ int carve_keys(const verify_params& P, key_params& K, uint8_t** cleared, size_t*
         C.key_bytes = 64;
         C.rep = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
         C.keyid = reinterpret_cast<uint32_t*>(p); p += pad256(P.n * 4);
+        C.valid_ids = reinterpret_cast<uint32_t*>(p); p += valid_bytes;
         uint8_t* q = sl->key_pool + (size_t)c * col_bytes;
         C.key_item = reinterpret_cast<uint32_t*>(q); q += L.item_bytes;
         C.key_flags = q; q += L.flag_bytes;

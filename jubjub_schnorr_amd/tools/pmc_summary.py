@@ -41,8 +41,8 @@ def read_counters(d):
             if not k:
                 continue
             out.setdefault(row["Counter_Name"], {}).setdefault(k, []).append(float(row["Counter_Value"]))
-            if k in DOMINANT and float(row["Counter_Value"]) > 0 and (k == "key_verify_kernel" or "dominant_kernel" not in meta):
-                meta = {"dominant_kernel": k, "grid_size": int(row["Grid_Size"]), "lds_block_size": int(row["LDS_Block_Size"]),
+            if k in DOMINANT and float(row["Counter_Value"]) > 0 and (k == "key_verify_kernel" or "equations_kernel" not in meta):
+                meta = {"equations_kernel": k, "grid_size": int(row["Grid_Size"]), "lds_block_size": int(row["LDS_Block_Size"]),
                         "scratch_size": int(row["Scratch_Size"]), "vgpr_count": int(row["VGPR_Count"]),
                         "sgpr_count": int(row["SGPR_Count"])}
     return out, meta
@@ -74,7 +74,7 @@ def main():
         c, m = read_counters(d)
         counters.update(c)
         meta = m or meta
-    summary = {"round": 3, "variant": variant, "csrc_sha256": bench.csrc_hash(),
+    summary = {"round": 4, "variant": variant, "csrc_sha256": bench.csrc_hash(),
                "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --scheme " + scheme + " --steps 3 --warmup 1 "
                           "--no-cpu-baseline (one pass per counter group); kernel times from a separate "
                           "rocprofv3 --kernel-trace --stats run",
@@ -126,6 +126,43 @@ def main():
             summary["effective_clock_note"] = ("not derived: key_chain / key_table overlap prepare_kernel, so neither the sum of "
                                                "kernel times nor the sum of per-dispatch busy cycles is the batch's; see the "
                                                "unique-keys summary (sequential kernels) and clock_power_*.jsonl")
+    # Per kernel, from its OWN counters of the PMC passes (rocprofv3 serialises dispatches while it collects counters, so
+    # these are the kernels one by one, not overlapped as in a batch): the issue bound 4 * I64 + 2 * (I - I64) SIMD-cycles
+    # against the SIMD-cycles the dispatch had, 1 024 SIMDs x GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs) -- a
+    # fraction that needs no clock.  `wait_inst_share`: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, the share of its resident time a
+    # wave spent waiting to issue (with w waves on a SIMD that is bound by issue, (w - 1) / w of it).  `trace_ms`: the
+    # dispatch in the batch as it runs (kernel trace, overlapped), `share_of_batch_time`: of the sum over kernels.
+    per_kernel = {}
+    total_trace = sum(v["avg_ms"] * v["calls"] / n_batches for v in stats.values()) or 1.0
+    for k in KERNELS:
+        valu = summary["counters"].get("SQ_INSTS_VALU", {}).get(k, {}).get("per_batch")
+        if valu is None:
+            continue
+        i64 = summary["counters"].get("SQ_INSTS_VALU_INT64", {}).get(k, {}).get("per_batch", 0.0)
+        grbm = summary["counters"].get("GRBM_GUI_ACTIVE", {}).get(k, {}).get("per_batch")
+        wave = summary["counters"].get("SQ_WAVE_CYCLES", {}).get(k, {}).get("per_batch")
+        wait = summary["counters"].get("SQ_WAIT_INST_ANY", {}).get(k, {}).get("per_batch")
+        waves = summary["counters"].get("SQ_WAVES", {}).get(k, {}).get("per_batch")
+        st = stats.get(k, {})
+        trace_ms = st.get("avg_ms", 0.0) * st.get("calls", 0) / n_batches
+        rec = {"valu_wave_instr": valu, "int64_share": (i64 / valu) if valu else None, "waves": waves, "trace_ms": trace_ms,
+               "share_of_batch_time": trace_ms / total_trace}
+        if grbm:
+            cycles = grbm / 8.0
+            rec["elapsed_cycles_alone"] = cycles
+            rec["alu_frac_alone"] = (4.0 * i64 + 2.0 * (valu - i64)) / (1024.0 * cycles)
+        if wave and wait is not None:
+            rec["wait_inst_share"] = wait / wave
+        per_kernel[k] = rec
+    summary["per_kernel"] = per_kernel
+    by_time = sorted(per_kernel, key=lambda k: -per_kernel[k]["trace_ms"])
+    summary["dominant_kernel"] = by_time[0] if by_time else None
+    summary["dominant_kernel_note"] = "by time in the batch (kernel trace); grid_size / vgpr_count / sgpr_count above are those of the equations kernel"
+    if unique and "key_table_kernel" in per_kernel:
+        summary["key_kernels_note"] = ("every signature under its own key: the key kernels decide against the tables and key_chain / key_table leave "
+                                       "at once (their instruction counts above); their trace_ms is the span from the first to the last of their "
+                                       "blocks being DISPATCHED on the lowest-priority streams, i.e. time spent waiting for wave slots beside "
+                                       "prepare_kernel, not time spent running (elapsed_cycles_alone is what they take by themselves)")
     suffix = ("" if scheme == "single" else "_" + scheme) + ("_unique_keys" if unique else "")
     summary["keys"] = "every signature under its own key (throughput path)" if unique else "4096 key pairs (SURVEY.md 8d; key-table path)"
     out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary{suffix}.json")
@@ -141,6 +178,11 @@ def main():
     latest["schemes"][scheme + ("_unique_keys" if unique else "")] = {"items": 1 << 20, "hbm_bytes_per_launch": summary.get("hbm_bytes_per_launch"),
                                  "valu_wave_instr_per_launch": summary.get("valu_wave_instr_per_launch"),
                                  "valu_int64_wave_instr_per_launch": summary.get("valu_int64_wave_instr_per_launch"),
+                                 "dominant_kernel": summary.get("dominant_kernel"),
+                                 "per_kernel": {k: {"alu_frac_alone": round(v["alu_frac_alone"], 4) if "alu_frac_alone" in v else None,
+                                                    "share_of_batch_time": round(v["share_of_batch_time"], 4),
+                                                    "valu_wave_instr": v["valu_wave_instr"]}
+                                                for k, v in per_kernel.items() if v["share_of_batch_time"] >= 0.02},
                                  "source": f"profiles/{tag}_pmc_summary{suffix}.json"}
     json.dump(latest, open(latest_path, "w"), indent=1)
     print(json.dumps({k: summary[k] for k in summary if k not in ("counters",)}, indent=1))

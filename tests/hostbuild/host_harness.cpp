@@ -133,12 +133,13 @@ static void run_keyed(verify_params P) {
         }
         const size_t nk = key_item[c].size();
         counters[c] = (uint32_t)nk;
-        flags[c].resize(nk + 1); bases[c].resize(nk * kt_positions(w) * KT_BASE_WORDS + 4); tables[c].resize(nk * kt_positions(w) * kt_table_words(w) + 8);
+        // (the pool of the device is not cleared between calls: an invalid key's tables, which nobody builds, are whatever lay there)
+        flags[c].resize(nk + 1); bases[c].resize(nk * kt_positions(w) * KT_BASE_WORDS + 4); tables[c].assign(nk * kt_positions(w) * kt_table_words(w) + 8, 0xA5C3F00Du);
         C.keyid = keyid[c].data(); C.key_item = key_item[c].data(); C.key_flags = flags[c].data();
         C.bases = bases[c].data();
         C.tables = (uint32_t*)(((uintptr_t)tables[c].data() + 15) & ~(uintptr_t)15);
         for (uint32_t id = 0; id < nk; ++id) {
-            kt_chain_key(C, id, w);
+            if (!kt_chain_key(C, id, w)) continue;           // as key_chain_kernel / key_table_kernel: tables for the valid keys only
             for (uint32_t pos = 0; pos < (uint32_t)kt_positions(w); ++pos) kt_table_lane(C, id, pos, w);
         }
     }
