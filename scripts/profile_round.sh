@@ -3,7 +3,7 @@
 # MI355X_MICROARCH.md prescribes), benches, phase profile with the gather ablation, clock / power sample.
 # Usage (through gpurun): bash scripts/profile_round.sh <tag> [schemes]  -> files under gpurun_out/, summaries in
 # profiles/<tag>_pmc_summary*.json and profiles/pmc_latest.json (stamped with the csrc hash)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r02}; SCHEMES=${2:-"single double vargen"}; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r04}; SCHEMES=${2:-"single double vargen"}; cd /tmp && export TMPDIR=/tmp
 for S in $SCHEMES single_unique; do
   KEYS=""; U=0; SS=$S
   if [ "$S" = "single_unique" ]; then SS=single; KEYS="--keys 1048576"; U=1; fi
@@ -18,16 +18,17 @@ for S in $SCHEMES single_unique; do
 done
 cd $R
 cp profiles/${T}_pmc_summary*.json profiles/pmc_latest.json gpurun_out/
-# the bench line the driver will record (all three schemes, CPU baselines), then wire / ext inputs
-timeout -k 10 400 python bench.py > gpurun_out/bench_${T}.json 2> gpurun_out/bench_${T}.err
+# the bench line the driver will record (all three schemes, CPU baselines, multisig, small host calls), then wire / ext inputs
+timeout -k 10 500 python bench.py > gpurun_out/bench_${T}.json 2> gpurun_out/bench_${T}.err
+cp gpurun_out/bench_full_n1.json gpurun_out/bench_${T}_full.json
 timeout -k 10 200 python bench.py --wire --no-cpu-baseline > gpurun_out/bench_${T}_wire.json 2>/dev/null
 timeout -k 10 200 python bench.py --ext --no-cpu-baseline > gpurun_out/bench_${T}_ext.json 2>/dev/null
+timeout -k 10 200 python bench.py --scheme multisig > gpurun_out/bench_${T}_multisig.json 2>/dev/null
 for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/phase_profile.py $s 20 2>/dev/null >> gpurun_out/phase_profile_${T}.jsonl; done
-timeout -k 10 200 python jubjub_schnorr_amd/tools/host_rate.py > gpurun_out/host_rate_${T}.json 2>/dev/null
-timeout -k 10 300 python jubjub_schnorr_amd/tools/multisig_rate.py > gpurun_out/multisig_rate_${T}.jsonl 2>/dev/null
 for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/batch_size_curve.py $s > gpurun_out/batch_size_curve_${T}_$s.jsonl 2>/dev/null; done
-timeout -k 10 200 python jubjub_schnorr_amd/tools/kt_window_ab.py > gpurun_out/kt_window_ab_${T}.jsonl 2>/dev/null
 timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_${T}.jsonl 2>/dev/null
-GPU_MAX_HW_QUEUES=8 timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_8_hw_queues_${T}.jsonl 2>/dev/null
+for s in single double vargen; do timeout -k 10 200 python -m jubjub_schnorr_amd.tools.tail_bound $s 3 >> gpurun_out/tail_bound_${T}.jsonl 2>/dev/null; done
+bash scripts/r04_small_calls.sh ${T} full
+bash scripts/timeline.sh ${T} single
 bash scripts/clock_sample.sh $T
 cut -c1-200 gpurun_out/bench_${T}.json; tail -3 gpurun_out/pmc_${T}_single.log
