@@ -42,10 +42,13 @@
  *
  * Threading: jjs_init / jjs_shutdown are not re-entrant.  All other calls may come from any host
  * thread.  One internal mutex guards the engine's state; it is held while a call is QUEUED, never while a call waits:
- * the *_dev calls are asynchronous, jjs_stream_sync waits outside it, and a blocking host-buffer call of at most
- * 131 072 items holds it only to take a staging lane (eight per device) and to queue its copies and launches, so that
- * such calls from several host threads run side by side on the device.  Larger host-buffer calls (each fills the device
- * by itself) run one at a time and hold the mutex for their duration.  A call takes one of the engine's call slots by size (three for calls of
+ * the *_dev calls are asynchronous, jjs_stream_sync waits outside it, and a blocking host-buffer call holds it only while
+ * its launches are queued.  Host-buffer calls of at most 16 384 items run on staging lanes (eight per device), side by side
+ * on the device; those of at most 4 096 items of one scheme and input format that arrive while another is running share
+ * one launch (JJS_PATH_LANE_LAUNCHES / JJS_PATH_LANE_CALLS count them): four threads of 1 024-signature calls complete
+ * three times the calls per second of one thread, eight threads five times.  Larger host-buffer calls are pipelines of
+ * uploads and launches that fill the device: they run one at a time per device (other threads' calls are queued meanwhile;
+ * with several driven devices such a call holds the mutex for its duration).  A call takes one of the engine's call slots by size (three for calls of
  * at most 16 384 items, three for at most 131 072, two for larger ones): calls in different slots share no buffer and
  * overlap on the device when they are issued on different streams; calls in one slot are ordered on the device (each
  * waits for the previous one, also across streams).

@@ -168,8 +168,11 @@ struct host_lane {
     char err[256] = "";
 };
 constexpr int N_HOST_LANES = 8;
+// The lanes take the calls of the latency path (at most 16 384 items: a copy of a few megabytes by the calling thread).  A
+// larger call goes through the piece-by-piece pipeline of host_calls.h, whose staging threads and overlapped uploads it needs
+// (131 072 single signatures: 2.45 ms there, 3.3-3.7 ms on a lane with one thread copying 25 MB ahead of one upload).
 #ifndef JJS_LANE_MAX_ITEMS
-#define JJS_LANE_MAX_ITEMS 131072
+#define JJS_LANE_MAX_ITEMS 16384
 #endif
 constexpr size_t LANE_MAX_ITEMS = JJS_LANE_MAX_ITEMS;
 #ifndef JJS_COMBINE_MAX_CALL_ITEMS
@@ -309,7 +312,14 @@ bool g_pin_hash_seed = false;     // set by jjs_debug_pin_hash_seed: the dedup h
 void pick_slot(size_t n, hipStream_t s) {
     if (forced_slot) { sl = forced_slot; return; }
     if (n <= SMALL_SLOT_ITEMS) { sl = &g->slots[1 + g->next_small]; g->next_small = (g->next_small + 1) % N_SMALL_SLOTS; }
-    else if (n <= MEDIUM_SLOT_ITEMS) { sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium]; g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS; }
+    else if (n <= MEDIUM_SLOT_ITEMS) {
+        // (not a slot that a host-buffer call is feeding outside the engine's mutex: at most one is)
+        for (int turn = 0; turn < N_MEDIUM_SLOTS; ++turn) {
+            sl = &g->slots[1 + N_SMALL_SLOTS + g->next_medium];
+            g->next_medium = (g->next_medium + 1) % N_MEDIUM_SLOTS;
+            if (!sl->host_owned) break;
+        }
+    }
     else {
         // a big slot is a big arena: calls that follow each other on one stream are ordered anyway and stay in one
         // slot; a call from another stream takes the other one if this one is still busy

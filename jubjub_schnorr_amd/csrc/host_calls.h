@@ -262,7 +262,7 @@ int run_host_block(device_state* dev, const host_col* cols, size_t n_cols, host_
         std::unique_lock<std::mutex> lock(L.mu, std::defer_lock);
         if (b.unlocked) lock.lock();
         if (int rc = build(in, nl, st, g->tally, g->stream, J.C)) return rc;
-        if (b.unlocked && nl > MEDIUM_SLOT_ITEMS) { sl->host_owned = true; b.owned = sl; }
+        if (b.unlocked) { sl->host_owned = true; b.owned = sl; }
     }
     bool late = false;
     for (size_t k = 0; k < n_cols; ++k) late = late || cols[k].group == COLS_LATE;
