@@ -46,7 +46,7 @@
  * its launches are queued.  Host-buffer calls of at most 16 384 items run on staging lanes (eight per device), side by side
  * on the device; those of at most 4 096 items of one scheme and input format that arrive while another is running share
  * one launch (JJS_PATH_LANE_LAUNCHES / JJS_PATH_LANE_CALLS count them): four threads of 1 024-signature calls complete
- * three times the calls per second of one thread, eight threads five times.  Larger host-buffer calls are pipelines of
+ * about three times the calls per second of one thread, eight threads four to five times.  Larger host-buffer calls are pipelines of
  * uploads and launches that fill the device: they run one at a time per device (other threads' calls are queued meanwhile;
  * with several driven devices such a call holds the mutex for its duration).  A call takes one of the engine's call slots by size (three for calls of
  * at most 16 384 items, three for at most 131 072, two for larger ones): calls in different slots share no buffer and
