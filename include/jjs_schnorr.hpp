@@ -64,6 +64,15 @@ class Engine {
   public:
     explicit Engine(int device_count = 1) { int rc = jjs_init(device_count); if (rc != JJS_OK) throw EngineError(rc, "jjs_init"); }
     int device_count() const { return jjs_device_count(); }
+    // Pre-sizes the engine for verify_batch calls of at most `max_items` items of one scheme (JJS_SCHEME_*) and input format
+    // (JJS_FORMAT_*): afterwards no such call allocates (include/jjs_gpu.h jjs_reserve).  The batch methods below are the
+    // blocking host-buffer calls, hence host_buffers = 1.
+    void reserve(int scheme, int format, size_t max_items) {
+        int rc = jjs_reserve(scheme, format, max_items, 1);
+        if (rc != JJS_OK) throw EngineError(rc, "jjs_reserve");
+    }
+    // Waits for the device, then gives back what growth has retired and the key-table pools (jjs_trim).
+    void trim() { int rc = jjs_trim(); if (rc != JJS_OK) throw EngineError(rc, "jjs_trim"); }
     ~Engine() { jjs_shutdown(); }
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;

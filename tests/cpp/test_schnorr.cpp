@@ -27,6 +27,7 @@ static int expect(const jjs::VerifyResult& got, int want, const std::string& nam
 int main(int argc, char** argv) {
     if (argc < 2) { std::puts("usage: test_schnorr vectors.txt"); return 2; }
     jjs::Engine engine;
+    engine.reserve(JJS_SCHEME_SINGLE, JJS_FORMAT_AFFINE, 4096);      // a service pre-sizes at start-up: no later call allocates
     std::ifstream in(argv[1]);
     std::string line;
     int failures = 0, n = 0;
