@@ -889,7 +889,6 @@ int jjs_reserve(int scheme, int format, size_t n_items, int host_buffers) {
     if (scheme < 0 || scheme > 2 || format < 0 || format > 2) return fail(JJS_ERR_ARG, "scheme / format out of range");
     if (n_items == 0) return JJS_OK;
     const call_shape& S = SHAPES[scheme][format];
-    struct unforce { ~unforce() { forced_slot = nullptr; } } unforce_on_every_way_out;
     return no_throw([&]() -> int {
         device_restore restore;
         std::vector<device_state*> targets;
