@@ -2,8 +2,8 @@
 var-generator signatures against the C
 restatement of the reference's algorithm on all host cores (~2 min of 16 threads): the device entry points (affine and
 wire) and the blocking host-buffer entry points (affine, extended, wire).
-JJS_SOAK_LOG2N overrides the size: the committed records profiles/r03_soak.json (round 2: r02z_soak.json) are runs with
-JJS_SOAK_LOG2N=20, i.e. BASELINE.json's configs[1], [2], [4] sizes (~3.7 min; the collected default is half of that so
+JJS_SOAK_LOG2N overrides the size: the committed record profiles/r04_soak.json (earlier rounds: history/r03_soak.json,
+history/r02z_soak.json) is a run with JJS_SOAK_LOG2N=20, i.e. BASELINE.json's configs[1], [2], [4] sizes (~3.7 min; the collected default is half of that so
 that the whole `-m gpu` suite stays near six minutes on a fresh box).  The JSON record lands in gpurun_out/soak.json."""
 import os
 
