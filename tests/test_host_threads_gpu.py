@@ -235,3 +235,28 @@ def test_small_calls_proceed_while_a_large_host_call_runs(eng):
     print(f"{len(log)} small calls, {inside} of them began and ended inside one of the 4 large calls "
           f"({(windows[-1][1] - windows[-1][0]) * 1e3:.1f} ms each)")
     assert inside >= 4, (inside, len(log))
+
+
+def test_lane_state_machine_under_sixteen_threads(eng, tmp_path):
+    """Sixteen pthreads, each rotating through twelve batches that differ in scheme, input format and size -- one item, a
+    ragged wave, sizes on both sides of the limit up to which calls combine (4 096) and the largest lane call (16 384) -- so
+    that lanes fill, close, launch and free in every order: joiners during the gather window, calls too large to combine
+    beside combined ones, more callers than lanes.  Every status and tally of every call against the C oracle."""
+    from jubjub_schnorr_amd.tools.small_host_calls import build_thread_client, c_threads, write_batches
+    specs = [("single", "affine", 1), ("single", "affine", 1000), ("double", "affine", 63), ("vargen", "affine", 4096),
+             ("single", "ext", 4097), ("single", "wire", 777), ("double", "wire", 2048), ("vargen", "ext", 300),
+             ("single", "affine", 16384), ("double", "ext", 5000), ("vargen", "wire", 1), ("single", "affine", 4096)]
+    work = []
+    for i, (scheme, fmt, n) in enumerate(specs):
+        b = make_batch(scheme, n, seed=7300 + i, n_keys=max(1, min(32, n // 8)))
+        want = oracle_verify(scheme, b)
+        args = {"affine": [b[k] for k in ARG_ORDER[scheme]], "ext": batch_to_extended(scheme, b, seed=i),
+                "wire": list(to_wire(scheme, b))}[fmt]
+        work.append((scheme, fmt, [np.ascontiguousarray(a) for a in args], want))
+    path = str(tmp_path / "many.bin")
+    write_batches(path, work)
+    exe = build_thread_client(str(tmp_path))
+    rec = c_threads(exe, path, [16], 36, rotate=True)[0]
+    print(rec)
+    assert rec["mismatches"] == 0 and rec["errors"] == 0, rec
+    assert rec["lane_calls"] == 16 * 36 and rec["lane_launches"] <= rec["lane_calls"]
