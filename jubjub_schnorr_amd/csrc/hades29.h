@@ -48,32 +48,45 @@ JJS_HD void hades_matrix(hades_state& o, const fe_n (&t)[5]) {
 // the host build and on the GPU).
 //
 // coop >= 0 (device only; the latency path, small_batch.h): eight adjacent lanes hold the same state and work on the
-// same permutation; in a full round lane j computes the S-box of state element min(j, 4) only and the five results
-// are exchanged (45 ds_bpermute), so a full round costs one S-box instead of five on the critical path.  The linear
-// layer and the partial rounds run redundantly on every lane.  Same arithmetic on the same values: same result.
+// same permutation.  In a full round lane j computes the S-box of state element min(j, 4) only and the five results are
+// exchanged (45 ds_bpermute), so a full round costs one S-box instead of five on the critical path.  The linear layer is
+// shared the same way in EVERY round: lane j computes row min(j, 4) of the matrix (fq_lincomb_small: 45 multiply-adds and
+// one Montgomery row, 74 instructions instead of the 370 of all five rows) and the five rows are exchanged -- 60 partial
+// rounds x ~250 instructions off the chain on which the whole call waits.  The S-box of a partial round runs redundantly
+// on every lane.  Same arithmetic on the same values: same result.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void hades_gather5(fe_n (&out)[5], const fe_n& mine, int base) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int w = 0; w < 9; ++w) out[i].l[w] = (uint32_t)__shfl((int)mine.l[w], base + i);
+    }
+}
+#endif
 JJS_HD void hades_permute(hades_state& st, int coop = -1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int cj = coop < 4 ? coop : 4, cbase = (int)(__lane_id() & ~7u);
+    uint32_t crow[5] = {0, 0, 0, 0, 0};         // this lane's row of the matrix: S[cj][k] = JJS_HS_HANKEL[cj + k]
+    if (coop >= 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) crow[k] = JJS_HS_HANKEL[cj + k];
+    }
+#endif
     for (int r = 0; r < 68; ++r) {
         fe_n t[5];
         if (r < 4 || r >= 64) {
             const int fr = r < 4 ? r : r - 60;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (coop >= 0) {
-                const int j = coop < 4 ? coop : 4;
                 fe_n x = st.s[4];
                 fe_c rc = fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][4]);
 #pragma unroll
                 for (int i = 3; i >= 0; --i) {
-                    x = fq_select(j == i, st.s[i], x);
-                    rc = fq_select(j == i, fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i]), rc);
+                    x = fq_select(cj == i, st.s[i], x);
+                    rc = fq_select(cj == i, fe_from_const<1, 1>(JJS_HS_RC_FULL[fr][i]), rc);
                 }
-                const fe_n mine = sbox5(fq_add(x, rc));
-                const int base = (int)(__lane_id() & ~7u);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-#pragma unroll
-                    for (int w = 0; w < 9; ++w) t[i].l[w] = (uint32_t)__shfl((int)mine.l[w], base + i);
-                }
-                hades_matrix(st, t);
+                hades_gather5(t, sbox5(fq_add(x, rc)), cbase);
+                hades_gather5(st.s, fq_lincomb_small<5>(crow, t), cbase);
                 continue;
             }
 #endif
@@ -84,6 +97,12 @@ JJS_HD void hades_permute(hades_state& st, int coop = -1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = st.s[i];
             t[4] = fq_mul(sbox5(fq_add(st.s[4], fe_from_const<1, 1>(JJS_HS_KAPPA[k]))), fe_from_const<1, 1>(JJS_HS_MU[k]));
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (coop >= 0) {
+                hades_gather5(st.s, fq_lincomb_small<5>(crow, t), cbase);
+                continue;
+            }
+#endif
         }
         hades_matrix(st, t);
     }
