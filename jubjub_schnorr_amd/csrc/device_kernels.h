@@ -333,6 +333,11 @@ __global__ __launch_bounds__(BLOCK, 2) void small_a_kernel(small_params S, uint3
         const uint32_t k = S.positions - 1 - cb / chain_blocks_per_pos;            // block-uniform position
         const uint64_t r = (uint64_t)(cb % chain_blocks_per_pos) * BLOCK + threadIdx.x;
         const uint32_t per_item = 2 * S.V.n_eq;                                     // (equation, PK | R)
+        if (S.quad_chains) {                                                        // four adjacent lanes per chain
+            const uint64_t q = r >> 2;
+            if (q < n * per_item) sb_chain_lane_quad(S, q / per_item, (uint32_t)(q % per_item) >> 1, (uint32_t)q & 1u, k, (uint32_t)r & 3u);
+            return;
+        }
         if (r < n * per_item) sb_chain_lane(S, r / per_item, (uint32_t)(r % per_item) >> 1, (uint32_t)r & 1u, k);
         return;
     }

@@ -412,6 +412,7 @@ int ensure_small(size_t bytes) {
 #define JJS_SMALL_ECONOMY_FROM 1
 #endif
 constexpr unsigned SMALL_ECONOMY_FROM = JJS_SMALL_ECONOMY_FROM;
+constexpr size_t SMALL_QUAD_CHAIN_MAX_ITEMS = 2048;      // see launch_small
 unsigned small_calls_in_flight() {
     unsigned k = 0;
     for (int i = 1; i <= N_SMALL_SLOTS; ++i) {
@@ -450,7 +451,12 @@ int launch_small(verify_params P, hipStream_t s) {
     // eight lanes per hash where the hash is the critical path (fixed generator) and the batch leaves lanes idle
     S.hash_lanes = (!vargen && small_fine_cut(P, others)) ? SB_HASH_LANES : 1;
     const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
-    const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 + BLOCK - 1) / BLOCK);
+    // The chains of a per-item-generator call on four lanes each: full-size scalars make its far positions 224 dependent
+    // doublings, which outlast the hash beside them (one call of 1 ... 2 048 such signatures: 0.83-0.92 -> 0.62-0.67 ms; at 4 096
+    // the fourfold chain lanes would be four waves per SIMD).  The fixed-generator schemes wait for their hash, not for their
+    // chains (112 doublings): the same switch does nothing for them (profiles/r04_quad_small_chains.jsonl).
+    S.quad_chains = (vargen && small_fine_cut(P, others) && P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS) ? 1u : 0u;
+    const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 * (S.quad_chains ? 4 : 1) + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + positions * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,
                        (uint32_t)hash_blocks, (uint32_t)chain_blocks);

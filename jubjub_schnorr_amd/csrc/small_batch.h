@@ -31,6 +31,7 @@
 // ~300 k dependent instructions instead of ~600 k, for ~1.8 x the total work: used below a size threshold only.
 #pragma once
 #include "verify_core.h"
+#include "ed29_quad.h"
 
 namespace jjs {
 
@@ -48,6 +49,8 @@ struct small_params {
     uint32_t windows;       // signed 4-bit windows of the scalars: 32 (half-size scalars, fixed generator) or 64 (per-item generator)
     uint32_t hash_lanes;    // 1, or SB_HASH_LANES: eight lanes share an item's challenge hash (smallest batches, where the
                             // hash is the critical path and the chip has lanes to spare)
+    uint32_t quad_chains;   // the doublings of a chain lane on four lanes (sb_chain_lane_quad): small calls of the per-item-
+                            // generator scheme, whose far positions (224 doublings) outlast the hash
 };
 
 JJS_HD uint32_t* sb_table(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k) {
@@ -93,6 +96,25 @@ JJS_HD void sb_chain_lane(const small_params& S, uint64_t item, uint32_t e, uint
     for (int i = 0; i < n_dbl; ++i) p = ext_double(p, i == n_dbl - 1);
     build_point_table_ext(tab, p);
 }
+#if defined(__HIPCC__)
+// The same on a quad (lane j of four adjacent lanes): the doublings shared (ext_double_quad: a third of the chain's latency),
+// the table built by lane 0.  Same products on the same limbs: the same table.
+__device__ __forceinline__ void sb_chain_lane_quad(const small_params& S, uint64_t item, uint32_t e, uint32_t pt, uint32_t k, uint32_t j) {
+    const fe_src& src = pt == 0 ? S.V.eq[e].pk : (S.V.eq[e].comb ? S.V.eq[e].r : S.V.eq[e].gen);
+    const fe_n pu = load_fq(src, item), pv = load_fq(src, item, 32);
+    uint32_t* tab = sb_table(S, item, e, pt, k);
+    if (k == 0) {                                    // wave-uniform: a launch gives every wave one position
+        if (j == 0) build_point_table(tab, pu, pv);
+        return;
+    }
+    ext_pt p = ext_from_affine(pu, pv);
+    const int n_dbl = 4 * ((int)S.windows / (int)S.positions) * (int)k;
+    fe_n own;
+#pragma unroll 1
+    for (int i = 0; i < n_dbl; ++i) p = ext_double_quad(p, j, own);
+    if (j == 0) build_point_table_ext(tab, p);
+}
+#endif
 // `is_valid` of one point (src/keys/public.rs:159-164, src/signatures.rs:93-98)
 JJS_HD void sb_point_lane(const small_params& S, uint64_t item, uint32_t p) {
     const fe_n pu = load_fq(S.V.points[p], item), pv = load_fq(S.V.points[p], item, 32);
