@@ -448,14 +448,16 @@ int launch_small(verify_params P, hipStream_t s) {
     S.point_ok = sl->small + table_bytes;
     S.positions = positions;
     S.windows = vargen ? 64 : 32;
-    // eight lanes per hash where the hash is the critical path (fixed generator) and the batch leaves lanes idle
-    S.hash_lanes = (!vargen && small_fine_cut(P, others)) ? SB_HASH_LANES : 1;
-    const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
+
     // The chains of a per-item-generator call on four lanes each: full-size scalars make its far positions 224 dependent
     // doublings, which outlast the hash beside them (one call of 1 ... 2 048 such signatures: 0.83-0.92 -> 0.62-0.67 ms; at 4 096
     // the fourfold chain lanes would be four waves per SIMD).  The fixed-generator schemes wait for their hash, not for their
     // chains (112 doublings): the same switch does nothing for them (profiles/r04_quad_small_chains.jsonl).
     S.quad_chains = (vargen && small_fine_cut(P, others) && P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS) ? 1u : 0u;
+    // eight lanes per hash where the hash is the critical path -- a fixed generator, or a per-item generator whose chains run on
+    // quads -- and the batch leaves lanes idle
+    S.hash_lanes = (small_fine_cut(P, others) && (!vargen || S.quad_chains)) ? SB_HASH_LANES : 1;
+    const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 * (S.quad_chains ? 4 : 1) + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(small_a_kernel, dim3(hash_blocks + positions * chain_blocks + point_blocks), dim3(BLOCK), 0, s, S,
