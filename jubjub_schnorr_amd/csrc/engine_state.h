@@ -163,11 +163,27 @@ struct host_lane {
     bool combinable_shape = false;    // a launch of combinable calls (LAUNCHED: no second one of its shape beside it)
     size_t cap = 0, items = 0;        // items the layout holds / items the members have claimed
     unsigned copying = 0, members = 0;
-    std::chrono::steady_clock::time_point gather_until{};    // not launched before (see COMBINE_WINDOW_US)
+    std::chrono::steady_clock::time_point gather_until{};    // not launched before (see COMBINE_WINDOW_US) ...
+#if defined(JJS_LANE_TRACE)
+    std::chrono::steady_clock::time_point trace_open{}, trace_done{};
+#endif
+    unsigned expect = 0;              // ... unless it has this many members: everybody the window is held open for has arrived
     int rc = 0;                       // outcome of the launch (JJS_OK or the error every member returns)
     char err[256] = "";
+    // bumped when the launch has ended (state DONE): what the members other than the lane's leader wait for, without the
+    // engine's mutex (host_lanes.h lane_await_done)
+    std::atomic<uint32_t> done_gen{0};
 };
 constexpr int N_HOST_LANES = 8;
+// A lane has ONE leader, the call that opened it: it waits for the lane to be complete and for its turn, launches, waits for
+// the device and publishes the outcome.  The other members only wait for `done_gen` -- polling it, as long as fewer than
+// LANE_MAX_SPINNERS threads of the process are polling for a lane already, else asleep on it (futex): a service with more
+// threads than cores (64 threads with one signature each is what the reference's one-item API makes of a busy node) must not
+// spend its cores on waiting, nor wake every waiter for every change of every lane.
+#ifndef JJS_LANE_MAX_SPINNERS
+#define JJS_LANE_MAX_SPINNERS 8
+#endif
+constexpr int LANE_MAX_SPINNERS = JJS_LANE_MAX_SPINNERS;
 // The lanes take the calls of the latency path (at most 16 384 items: a copy of a few megabytes by the calling thread).  A
 // larger call goes through the piece-by-piece pipeline of host_calls.h, whose staging threads and overlapped uploads it needs
 // (131 072 single signatures: 2.45 ms there, 3.3-3.7 ms on a lane with one thread copying 25 MB ahead of one upload).
@@ -181,12 +197,18 @@ constexpr size_t LANE_MAX_ITEMS = JJS_LANE_MAX_ITEMS;
 constexpr size_t COMBINE_MAX_CALL_ITEMS = JJS_COMBINE_MAX_CALL_ITEMS, COMBINE_CAP_ITEMS = 16384;      // the cap: what the latency path takes
 // When a launch ends, the lane that has been filling behind it is not launched before this many microseconds have passed:
 // the threads that launch served come back within microseconds of each other and find it still open.  (Launched at once, it
-// would leave without them, and the threads would take turns in half-empty launches.)  A caller that finds no launch of its
-// shape running does not wait.
+// would leave without them, and the threads would take turns in half-empty launches.)  The same holds for a lane that is
+// opened just behind a launch that carried several calls (its first returning caller): two threads would otherwise alternate
+// between launches of two calls and of one.  The window closes early when as many calls have joined as the launch released
+// (plus those that were waiting already).  A caller that finds no launch of its shape running, and none of several calls
+// just ended, does not wait.
 #ifndef JJS_COMBINE_WINDOW_US
 #define JJS_COMBINE_WINDOW_US 50
 #endif
 constexpr unsigned COMBINE_WINDOW_US = JJS_COMBINE_WINDOW_US;
+#ifndef JJS_COMBINE_EXPECT
+#define JJS_COMBINE_EXPECT 1        // 0 (A/B builds): the window is always held for its whole length, and only behind a running launch
+#endif
 // A buffer that was replaced by a larger one.  It may still be in use by launches that are in flight, and hipFree would
 // wait for every stream of the device: it is kept until jjs_trim / jjs_shutdown (grow-only buffers grow geometrically, so
 // what is kept is less than what is live).
@@ -231,8 +253,11 @@ struct device_state {
     size_t pinned_bytes = 0;
     hipEvent_t chunk_up[HOST_MAX_PIECES] = {}, chunk_done[HOST_MAX_PIECES] = {};   // per piece of a host-buffer call: uploaded, converted
     host_lane lanes[N_HOST_LANES];       // small and medium host-buffer calls: one lane per launch in flight or filling
-    std::atomic<uint64_t> lane_epoch{0}; // bumped (under the engine's mutex) whenever a lane changes state: what waiting callers poll
+    std::atomic<uint64_t> lane_epoch{0}; // bumped (under the engine's mutex) whenever a lane changes state: what lane leaders and callers without a lane poll
+    std::atomic<int> lane_spinners{0};   // threads polling for a lane right now (at most LANE_MAX_SPINNERS; the others sleep)
     size_t lane_last_items[3][3] = {};   // [scheme][format]: items of the last combined launch (sizes the next lane)
+    unsigned lane_last_members[3][3] = {};   // ... the calls it carried, and when it ended: the callers it released are about to
+    std::chrono::steady_clock::time_point lane_last_done[3][3] = {};   // come back, and the next lane waits for them (COMBINE_WINDOW_US)
     std::vector<retired_buffer> retired; // replaced buffers, freed by jjs_trim / jjs_shutdown
     size_t retired_bytes = 0;
 };

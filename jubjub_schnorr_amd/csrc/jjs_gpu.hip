@@ -34,6 +34,10 @@
 #include <mutex>
 #include <random>
 #include <sched.h>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -293,6 +297,9 @@ struct device_restore {   // puts the calling thread back on the device it came 
 
 extern "C" {
 
+#if defined(JJS_LANE_TRACE)
+static void lane_trace_dump();     // host_lanes.h, investigation builds
+#endif
 int jjs_abi_version(void) { return 5; }
 const char* jjs_last_error(void) { return t_err; }
 
@@ -348,6 +355,9 @@ void jjs_shutdown(void) {
     });
     shutdown_locked();
     L.lane_cv.notify_all();
+#if defined(JJS_LANE_TRACE)
+    lane_trace_dump();
+#endif
 }
 
 int jjs_device_count(void) {

@@ -204,9 +204,10 @@ def c_threads(exe, batch_file, thread_counts, calls, rotate=False):
 
 
 def measure(eng, bench, schemes=("single",), formats=("affine", "ext", "wire"), sizes=(1, 64, 1024, 4096, 16384),
-            thread_counts=(1, 4, 8), n_thread=1024, calls=200):
+            thread_counts=(1, 4, 8), n_thread=1024, calls=200, one_item_threads=(1, 8, 64)):
     """What bench.py quotes: per scheme the latency table (one python thread), and for the first scheme the thread scaling of
-    the affine calls from the C client (pthreads)."""
+    the affine calls from the C client (pthreads): calls of n_thread items, and calls of ONE item -- the reference's own API
+    (one signature per call, src/keys/public.rs:114-118) from a service's threads."""
     import tempfile
     rec, ok = {"unit": "ms per blocking call, pageable host arrays in, statuses out", "ms_per_call": {}}, True
     for s in schemes:
@@ -216,19 +217,23 @@ def measure(eng, bench, schemes=("single",), formats=("affine", "ext", "wire"), 
     s = schemes[0]
     tmp = tempfile.mkdtemp(prefix="jjs_threads_")
     exe = build_thread_client(tmp)
-    batches = []
-    for t in range(max(thread_counts)):
-        arrays, expect = bench.make_inputs(eng, s, n_thread, 100 + t, n_keys=max(2, n_thread // 16))
-        batches.append((s, "affine", formats_of(eng, bench, s, arrays, seed=7 + t)["affine"], expect.cpu().numpy()))
-    path = os.path.join(tmp, "batches.bin")
-    write_batches(path, batches)
-    recs = c_threads(exe, path, thread_counts, calls)
-    one = recs[0]["calls_per_s"]
-    rec["threads"] = {"scheme": s, "format": "affine", "items_per_call": n_thread, "calls_per_thread": calls, "client": "tests/c/thread_client.c (pthreads)",
-                      "calls_per_s": {str(r["threads"]): round(r["calls_per_s"]) for r in recs},
-                      "speedup_over_one_thread": {str(r["threads"]): round(r["calls_per_s"] / one, 2) for r in recs},
-                      "calls_per_launch": {str(r["threads"]): round(r["lane_calls"] / max(1, r["lane_launches"]), 2) for r in recs}}
-    rec["bit_exact"] = bool(ok and all(r["mismatches"] == 0 and r["errors"] == 0 for r in recs))
+    for key, n_call, counts in (("threads", n_thread, thread_counts), ("threads_one_item_calls", 1, one_item_threads)):
+        if not counts:
+            continue
+        batches = []
+        for t in range(max(counts)):
+            arrays, expect = bench.make_inputs(eng, s, n_call, 100 + t, n_keys=max(2, n_call // 16))
+            batches.append((s, "affine", formats_of(eng, bench, s, arrays, seed=7 + t)["affine"], expect.cpu().numpy()))
+        path = os.path.join(tmp, "batches_%d.bin" % n_call)
+        write_batches(path, batches)
+        recs = c_threads(exe, path, counts, calls)
+        one = recs[0]["calls_per_s"]
+        rec[key] = {"scheme": s, "format": "affine", "items_per_call": n_call, "calls_per_thread": calls, "client": "tests/c/thread_client.c (pthreads)",
+                    "calls_per_s": {str(r["threads"]): round(r["calls_per_s"]) for r in recs},
+                    "speedup_over_one_thread": {str(r["threads"]): round(r["calls_per_s"] / one, 2) for r in recs},
+                    "calls_per_launch": {str(r["threads"]): round(r["lane_calls"] / max(1, r["lane_launches"]), 2) for r in recs}}
+        ok = ok and all(r["mismatches"] == 0 and r["errors"] == 0 for r in recs)
+    rec["bit_exact"] = bool(ok)
     return rec
 
 
