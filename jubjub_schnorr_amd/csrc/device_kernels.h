@@ -329,6 +329,9 @@ __global__ __launch_bounds__(BLOCK, 2) void small_a_kernel(small_params S, uint3
         return;
     }
     const uint32_t cb = b - hash_blocks;
+#if defined(JJS_AB_SMALL_ONLY_HASH)        // timing experiments: the hash lanes alone (results are garbage)
+    return;
+#endif
     if (cb < S.positions * chain_blocks_per_pos) {
         const uint32_t k = S.positions - 1 - cb / chain_blocks_per_pos;            // block-uniform position
         const uint64_t r = (uint64_t)(cb % chain_blocks_per_pos) * BLOCK + threadIdx.x;

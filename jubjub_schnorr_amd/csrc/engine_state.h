@@ -437,7 +437,7 @@ int ensure_small(size_t bytes) {
 #define JJS_SMALL_ECONOMY_FROM 1
 #endif
 constexpr unsigned SMALL_ECONOMY_FROM = JJS_SMALL_ECONOMY_FROM;
-constexpr size_t SMALL_QUAD_CHAIN_MAX_ITEMS = 2048;      // see launch_small
+constexpr size_t SMALL_QUAD_CHAIN_MAX_ITEMS = 2048, SMALL_QUAD_CHAIN_MAX_ITEMS_FIXED = 1024;      // see launch_small (per-item generator, fixed generator)
 unsigned small_calls_in_flight() {
     unsigned k = 0;
     for (int i = 1; i <= N_SMALL_SLOTS; ++i) {
@@ -474,11 +474,14 @@ int launch_small(verify_params P, hipStream_t s) {
     S.positions = positions;
     S.windows = vargen ? 64 : 32;
 
-    // The chains of a per-item-generator call on four lanes each: full-size scalars make its far positions 224 dependent
-    // doublings, which outlast the hash beside them (one call of 1 ... 2 048 such signatures: 0.83-0.92 -> 0.62-0.67 ms; at 4 096
-    // the fourfold chain lanes would be four waves per SIMD).  The fixed-generator schemes wait for their hash, not for their
-    // chains (112 doublings): the same switch does nothing for them (profiles/r04_quad_small_chains.jsonl).
-    S.quad_chains = (vargen && small_fine_cut(P, others) && P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS) ? 1u : 0u;
+    // The chains on four lanes each (sb_chain_lane_quad) while the call leaves lanes idle: the far positions of a per-item-
+    // generator call are 224 dependent doublings (full-size scalars), which outlast the hash beside them (one call of 1 ...
+    // 2 048 such signatures: 0.83-0.92 -> 0.62-0.67 ms; at 4 096 the fourfold chain lanes would be four waves per SIMD); those of
+    // the fixed-generator schemes 112, which the hash outlasted until its chain was cut to three products a round
+    // (hades29.h): since then 0.44-0.46 -> 0.40-0.42 ms for one call of 1 ... 1 024 single signatures
+    // (profiles/r04_quad_small_chains.jsonl, r04_small_call_chain.jsonl).
+    // (the double scheme gains nothing at any size, and single calls nothing beyond 1 024 items: profiles/r04_small_call_chain.jsonl)
+    S.quad_chains = (small_fine_cut(P, others) && (vargen ? P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS : (P.n_eq == 1 && P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS_FIXED))) ? 1u : 0u;
     // eight lanes per hash where the hash is the critical path -- a fixed generator, or a per-item generator whose chains run on
     // quads -- and the batch leaves lanes idle
     S.hash_lanes = (small_fine_cut(P, others) && (!vargen || S.quad_chains)) ? SB_HASH_LANES : 1;

@@ -369,6 +369,31 @@ JJS_HD fe_n fq_sqr_plus_const(const fe<2, Aa>& a) {
     return o;
 }
 
+// The products of the cooperative hash (hades29.h, coop >= 0; nobody else may call them) with the blocks inlined: that path
+// is a single dependent chain on which a whole small call waits, and a call costs ~25 register moves each way.  The operands
+// may be (normalised limbs + a Hades round constant): a square of such a value has the column sums of fq_sqr_plus_const
+// (checked for every constant at generation time), its product with itself the same sums, its product with a value of
+// normalised limbs sums below 9 * 2^59.
+template <int La, int Aa, int Lb, int Ab>
+JJS_HD fe_n fq_mul_chain(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
+    static_assert(La * Lb <= 4 && Aa * Ab <= 70, "see fq_mul / fq_mul_plus_const");
+    raw9 r = mont_mul_inl(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8],
+                          b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8]);
+    fe_n o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = r.l[i];
+    return o;
+}
+template <int La, int Aa>
+JJS_HD fe_n fq_sqr_chain(const fe<La, Aa>& a) {
+    static_assert(La <= 2 && Aa * Aa <= 70, "see fq_sqr / fq_sqr_plus_const");
+    raw9 r = mont_sqr_inl(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8]);
+    fe_n o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = r.l[i];
+    return o;
+}
+
 template <int La, int Aa, int Lb, int Ab>
 JJS_HD fe_n fq_mul(const fe<La, Aa>& a, const fe<Lb, Ab>& b) {
     static_assert(La * Lb <= 3, "product columns would overflow the signed 64-bit accumulator: normalise an operand");

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel durations of one small call under rocprofv3 --kernel-trace: small_a_kernel (hash | chains | point checks side by
 side) and small_b_kernel, with the full call and with the challenge hash skipped (profiling build), i.e. which of phase A's
-roles the call waits for.  Usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/small_call_trace.py <scheme> <n> [skip]"""
+roles the call waits for.  Usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/small_call_trace.py <scheme> <n> [skip] [lib]"""
 import os
 import sys
 
@@ -14,7 +14,9 @@ from jubjub_schnorr_amd import _ffi  # noqa: E402
 
 scheme, n = sys.argv[1], int(sys.argv[2])
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-if skip:
+if len(sys.argv) > 4:                                # a variant build (A/B runs)
+    _ffi.select_library(os.path.abspath(sys.argv[4]))
+elif skip:
     _ffi.select_library(_ffi.PROFILING_LIB_PATH)
 import jubjub_schnorr_amd as jjs  # noqa: E402
 eng = jjs.engine()
