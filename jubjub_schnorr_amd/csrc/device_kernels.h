@@ -387,7 +387,8 @@ __global__ __launch_bounds__(BLOCK, 2) void small_b_kernel(small_params S) {
     ext_pt acc = sb_piece(S, item, e, k, r);
     acc = sb_add(acc, dpp_quad<0xB1>(acc));       // quad_perm [1,0,3,2]: partner lane ^ 1
     acc = sb_add(acc, dpp_quad<0x4E>(acc));       // quad_perm [2,3,0,1]: partner lane ^ 2
-    if (pos == 8) acc = sb_add(acc, shfl_xor_ext(acc, 4));
+    if (pos >= 8) acc = sb_add(acc, shfl_xor_ext(acc, 4));
+    if (pos == 16) acc = sb_add(acc, shfl_xor_ext(acc, 8));
     bool eq_ok = sb_equation_holds(S, item, e, acc);
     if (S.V.n_eq == 2) eq_ok = (__shfl_xor((int)eq_ok, (int)pos) != 0) && eq_ok;
     const uint32_t st = sb_status(r.malformed, sb_points_ok(S, item), eq_ok);

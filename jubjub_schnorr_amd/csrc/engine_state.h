@@ -325,7 +325,7 @@ int grid_for(int resident, size_t n) {
 uint32_t g_skip_phases = 0;       // set by jjs_debug_skip_phases (libjjs_gpu_prof.so only)
 bool g_allow_virtual = false;     // set by jjs_debug_allow_virtual_devices (libjjs_gpu_prof.so only)
 int g_force_path = 0;             // set by jjs_debug_force_path: 0 = by size, 1 = throughput path, 2 = latency path
-int g_force_positions = 0;        // ... and 4 or 8 pieces on the latency path (0 = by size)
+int g_force_positions = 0;        // ... and 4, 8 or 16 pieces on the latency path (0 = by size)
 double g_host_timing[8] = {};     // last host-buffer call, seconds: see jjs_debug_host_timing (include/jjs_gpu_profiling.h)
 bool g_keep_order = false;        // ... 0x1000: key-table path without grouping the items by key
 int g_force_window = 0;           // ... 5: narrow windows on the key-table path whatever the signatures per key
@@ -451,21 +451,33 @@ bool small_fine_cut(const verify_params& P, unsigned others) {
     const bool vargen = P.eq[0].comb == nullptr;
     return P.n <= (vargen ? SMALL_PATH_FINE_ITEMS_VARGEN : SMALL_PATH_FINE_ITEMS[P.n_eq]) && others < SMALL_ECONOMY_FROM;
 }
+// Sixteen pieces for the smallest calls that are alone: phase B (the tail behind the hash) is two windows per lane instead of
+// four, for twice the chain lanes.  One call, 16 against 8 pieces (profiles/r04_small_call_chain.jsonl): single 0.365-0.38
+// against 0.40-0.41 ms up to 512 items (1 024: 0.45 against 0.42); double 0.50-0.54 against 0.525-0.56 up to 1 024; per-item
+// generator 0.41-0.42 against 0.46 up to 256 (512: equal; 1 024: 0.61 against 0.53).
+constexpr size_t SMALL_PATH_FINEST_ITEMS[3] = {0, 512, 1024}, SMALL_PATH_FINEST_ITEMS_VARGEN = 256;      // by number of equations
+bool small_finest_size(const verify_params& P) {
+#if defined(JJS_AB_NO_FINEST_CUT)
+    return false;
+#endif
+    return P.n <= (P.eq[0].comb == nullptr ? SMALL_PATH_FINEST_ITEMS_VARGEN : SMALL_PATH_FINEST_ITEMS[P.n_eq]);
+}
 uint32_t small_positions(const verify_params& P, unsigned others) {
-    uint32_t positions = small_fine_cut(P, others) ? 8 : 4;
+    uint32_t positions = small_fine_cut(P, others) ? (small_finest_size(P) ? 16 : 8) : 4;
 #if defined(JJS_PROFILING)
     if (g_force_positions) positions = (uint32_t)g_force_positions;
 #endif
     return positions;
 }
 size_t small_table_bytes(const verify_params& P, uint32_t positions) { return P.n * sb_table_words_per_item(P.n_eq, positions) * sizeof(uint32_t); }
+// the tables of the finest cut a call of this size can take (a slot sized for them holds any coarser cut)
+size_t small_table_bytes_max(const verify_params& P) { return small_table_bytes(P, small_finest_size(P) ? 16 : 8); }
 int launch_small(verify_params P, hipStream_t s) {
     const bool vargen = P.eq[0].comb == nullptr;
     const unsigned others = small_calls_in_flight();
     const uint32_t positions = small_positions(P, others);
     const size_t table_bytes = small_table_bytes(P, positions);
-    // (the tables of the fine cut are the larger ones: a slot sized for them holds either)
-    if (int rc = ensure_small(small_table_bytes(P, 8) + 4 * P.n + 64)) return rc;
+    if (int rc = ensure_small((positions > 8 ? small_table_bytes(P, positions) : small_table_bytes_max(P)) + 4 * P.n + 64)) return rc;
     small_params S{};
     P.small_mode = 1;
     S.V = P;

@@ -1064,7 +1064,7 @@ int jjs_debug_skip_phases(unsigned mask) {
 int jjs_debug_force_path(int which) {
     std::lock_guard<std::mutex> lock(L.mu);
     g_force_path = which & 3;                       // 0 by size and keys, 1 throughput (key tables allowed), 2 latency, 3 throughput without key tables
-    g_force_positions = ((which >> 4) & 15) == 4 || ((which >> 4) & 15) == 8 ? ((which >> 4) & 15) : 0;    // 0x42 / 0x82: latency path, 4 / 8 pieces
+    g_force_positions = ((which >> 4) & 15) == 4 || ((which >> 4) & 15) == 8 ? ((which >> 4) & 15) : (((which >> 4) & 15) == 15 ? 16 : 0);    // 0x42 / 0x82 / 0xF2: latency path, 4 / 8 / 16 pieces
     g_keep_order = (which & 0x1000) != 0;
     g_force_window = ((which >> 8) & 15) == KT_WINDOW_NARROW ? ((which >> 8) & 15) : 0;   // 0x500: narrow key-table windows whatever the keys
     return JJS_OK;

@@ -35,17 +35,17 @@
 
 namespace jjs {
 
-// The 128-bit half-size scalars are cut into `positions` pieces (4 or 8, chosen per launch: the finer cut halves
-// the tail of the critical path again and doubles the work of the chain lanes, so it is used for the smallest
+// The 128-bit half-size scalars are cut into `positions` pieces (4, 8 or 16, chosen per launch: a finer cut halves
+// the tail of the critical path again and doubles the work of the chain lanes, so it is used for the smaller
 // batches only).  Piece k covers bits [128 k / positions, 128 (k + 1) / positions).
-constexpr int SB_MAX_POSITIONS = 8;
+constexpr int SB_MAX_POSITIONS = 16;
 static_assert(COMB_WINDOWS % SB_MAX_POSITIONS == 0, "the comb digits are shared out evenly");
 
 struct small_params {
     verify_params V;        // scheme descriptor with small_mode = 1; V.prep holds the prep records
     uint32_t* tables;       // [item][equation][0 = PK, 1 = R][position][TABLE_WORDS]
     uint8_t* point_ok;      // [item][4]: V.points[p] is on the curve, not the identity, torsion-free
-    uint32_t positions;     // 4 or 8
+    uint32_t positions;     // 4, 8 or 16
     uint32_t windows;       // signed 4-bit windows of the scalars: 32 (half-size scalars, fixed generator) or 64 (per-item generator)
     uint32_t hash_lanes;    // 1, or SB_HASH_LANES: eight lanes share an item's challenge hash (smallest batches, where the
                             // hash is the critical path and the chip has lanes to spare)

@@ -224,7 +224,7 @@ bool small_path_applies(const verify_params& P) {
 // jjs_reserve: the slot buffers a call with this descriptor would allocate (the slot is `sl`), allocated now
 int reserve_for(const verify_params& P) {
     if (int rc = ensure_prep(P.n)) return rc;
-    if (small_path_applies(P)) return ensure_small(small_table_bytes(P, 8) + 4 * P.n + 64);
+    if (small_path_applies(P)) return ensure_small(small_table_bytes_max(P) + 4 * P.n + 64);
     if (int rc = ensure_pending(P.n)) return rc;
     if (key_path_applies(P)) {
         key_params K{};

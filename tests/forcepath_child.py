@@ -26,7 +26,7 @@ def main() -> None:
         cases += [edge_cases(scheme), torsion_grid(scheme, reps=2, extra=0 if scheme == "single" else 100)]
         for b in cases:
             want = oracle_verify(scheme, b)
-            for path in (1, 0x42, 0x82):        # throughput path; latency path with 4 and with 8 pieces
+            for path in (1, 0x42, 0x82, 0xF2):        # throughput path; latency path with 4, 8 and 16 pieces
                 assert lib.jjs_debug_force_path(path) == 0
                 st, tally = eng.verify(scheme, *[dev(b[k]) for k in ARG_ORDER[scheme]])
                 assert st.cpu().numpy().tolist() == want.tolist(), (scheme, len(want), path)

@@ -423,7 +423,7 @@ def test_normalize_extended_points():
 
 
 # ---- latency path for small batches (csrc/small_batch.h) -----------------------------------------------------
-@pytest.mark.parametrize("positions", [4, 8])
+@pytest.mark.parametrize("positions", [4, 8, 16])
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
 def test_small_batch_path_matches_oracle(scheme, positions):
     """The same statuses from the path that cuts a signature into chain / point / hash / piece lanes: mixed batch,
