@@ -508,13 +508,17 @@ __global__ __launch_bounds__(BLOCK) void msig_kernel(msig_params P, int pass) {
     uint32_t* ws = P.lane_ws + gtid * WS_WORDS_PER_LANE;
     const bool per_transcript = (pass == 0 || pass == 2 || pass == 4 || pass == 6);
     const uint64_t count = per_transcript ? P.n_transcripts : P.n_total;
-    for (uint64_t i = gtid; i < count; i += total) {
+    // the passes with a hash chain, on eight lanes per item when the call has few of them (whole groups of eight adjacent lanes
+    // enter and leave the loop together: the shuffles of a group stay inside it)
+    const uint32_t hl = (pass == 1 || pass == 2 || pass == 4) ? P.hash_lanes : 1u;
+    const int coop = hl > 1 ? (int)(gtid % hl) : -1;
+    for (uint64_t i = gtid / hl; i < count; i += total / hl) {
         switch (pass) {
         case 0: msig_map_item(P, (uint32_t)i); break;
-        case 1: msig_delin_item(P, i, ws); break;
-        case 2: msig_agg_item(P, (uint32_t)i); break;
+        case 1: msig_delin_item(P, i, ws, coop); break;
+        case 2: msig_agg_item(P, (uint32_t)i, coop); break;
         case 3: msig_commit_item(P, i, ws); break;
-        case 4: msig_final_item(P, (uint32_t)i); break;
+        case 4: msig_final_item(P, (uint32_t)i, coop); break;
         case 5: msig_share_item(P, i, ws); break;
         default: msig_verdict_item(P, (uint32_t)i); break;
         }

@@ -315,6 +315,10 @@ int fail(int code, const char* fmt, ...) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Multisignature passes that hash (delinearisation, a, c) take eight lanes per item while that still leaves the device a wave per
+// SIMD: a transcript's sponge is ONE chain of (3 + 4 n) / 4 permutations, and eight lanes run a permutation in 0.12 ms instead
+// of 0.25 (hades29.h, coop).  Beyond, the passes are throughput-bound and eight lanes per item would be eight times the work.
+constexpr size_t MSIG_COOP_MAX_ITEMS = 8192;
 int grid_for(int resident, size_t n) {
     size_t want = (n + BLOCK - 1) / BLOCK;
     if (want < 1) want = 1;

@@ -896,7 +896,9 @@ int jjs_multisig_combine_dev(const void* z, const void* PK, const void* R, const
         HIP_TRY(hipMemcpyAsync(d_off, offsets_host, (n_transcripts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         for (int pass = 0; pass < 7; ++pass) {
             const size_t count = (pass == 0 || pass == 2 || pass == 4 || pass == 6) ? n_transcripts : n;
-            hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g->grid_msig, count)), dim3(BLOCK), 0, s, P, pass);
+            // a pass with a hash chain and few items: eight lanes per item (multisig_core.h hash_lanes)
+            P.hash_lanes = ((pass == 1 || pass == 2 || pass == 4) && count <= MSIG_COOP_MAX_ITEMS) ? 8u : 1u;
+            hipLaunchKernelGGL(msig_kernel, dim3(grid_for(g->grid_msig, count * P.hash_lanes)), dim3(BLOCK), 0, s, P, pass);
         }
         HIP_TRY(hipGetLastError());
         return JJS_OK;

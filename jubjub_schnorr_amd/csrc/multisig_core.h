@@ -7,8 +7,9 @@
 //   combine                  src/multisig.rs:326-360  (u = sum z_i, R = RSa)
 //   aggregate_pk             src/multisig.rs:154-156
 // Like the reference these functions do not validate the points (they take JubJubExtended values);
-// only the encodings are checked (status 3).  Six passes, each one lane per participant or per
-// transcript; the hash chains (2 + 2n and 3 + 4n inputs) run inside a lane.
+// only the encodings are checked (status 3).  Seven passes, each one lane per participant or per
+// transcript; the hash chains (2 + 2n and 3 + 4n inputs) run inside a lane -- or, when the call has few lanes (a long
+// transcript or two: the sponge is one chain of (3 + 4n) / 4 permutations), on eight lanes each (msig_params::hash_lanes).
 #pragma once
 #include "sign_core.h"
 #include "safe_tag.h"
@@ -30,7 +31,10 @@ struct msig_params {
     const uint32_t* tags;                // SAFE tags [JJS_LONG_TAGS][9]: transcripts of up to JJS_MSIG_MAX_PARTICIPANTS participants
     uint32_t* long_tags;                 // scratch [B][2][9]: the two tags of every longer transcript, computed by pass 0
                                          // (csrc/safe_tag.h); rows of the other transcripts are neither written nor read
-    uint32_t max_table_participants, pad2_;
+    uint32_t max_table_participants;
+    uint32_t hash_lanes;                 // 1, or 8 (device, passes 1, 2 and 4 of a call with few lanes: hades_permute's coop mode -- eight
+                                         // adjacent lanes run the item together, sharing its hash; everything else they do eight times over,
+                                         // every lane storing the same values)
     const uint32_t* comb_g;
     uint32_t* lane_ws;                   // WS_WORDS_PER_LANE per resident lane
 };
@@ -70,13 +74,13 @@ JJS_HD void msig_map_item(const msig_params& P, uint32_t t) {
     }
 }
 // pass 1 (lane per participant): d_i = H(pk_i, pk_lo .. pk_hi), D_i = d_i * PK_i
-JJS_HD void msig_delin_item(const msig_params& P, uint64_t i, uint32_t* ws) {
+JJS_HD void msig_delin_item(const msig_params& P, uint64_t i, uint32_t* ws, int coop = -1) {
     const uint32_t t = P.tr_of[i], lo = P.offsets[t], hi = P.offsets[t + 1];
     const int n_in = 2 + 2 * (int)(hi - lo);
     const fe_src pk{P.PK, 64, 0};
     fe_n dg = poseidon_digest_tagged(n_in, msig_tag(P, t, hi - lo, 0, n_in), [&](int e) {
         return e < 2 ? load_fq(pk, i, 32u * (uint32_t)e) : load_fq(pk, lo + (uint64_t)((e - 2) >> 1), 32u * (uint32_t)(e & 1));
-    });
+    }, coop);
     const words8 d = truncate250(dg);
     store_w8(P.d_words + 8 * i, d);
     build_point_table(ws, load_fq(pk, i), load_fq(pk, i, 32));
@@ -88,7 +92,7 @@ JJS_HD affine_words sum_points_affine(const uint32_t* pts, uint32_t lo, uint32_t
     return to_affine_words(acc);
 }
 // pass 2 (lane per transcript): pk_agg = sum D_i;  a = H(pk_agg, m, R_lo, S_lo, ...)
-JJS_HD void msig_agg_item(const msig_params& P, uint32_t t) {
+JJS_HD void msig_agg_item(const msig_params& P, uint32_t t, int coop = -1) {
     const uint32_t lo = P.offsets[t], hi = P.offsets[t + 1];
     const affine_words agg = sum_points_affine(P.dpk, lo, hi);
     store_point(P.agg_pk, t, agg);
@@ -100,7 +104,7 @@ JJS_HD void msig_agg_item(const msig_params& P, uint32_t t) {
         const int k = e - 3;                     // R_i.u, R_i.v, S_i.u, S_i.v per participant
         const uint64_t idx = lo + (uint64_t)(k >> 2);
         return (k & 2) ? load_fq(ss, idx, 32u * (uint32_t)(k & 1)) : load_fq(rs, idx, 32u * (uint32_t)(k & 1));
-    });
+    }, coop);
     store_w8(P.a_words + 8 * t, truncate250(dg));
 }
 // pass 3 (lane per participant): E_i = R_i + a * S_i
@@ -113,14 +117,14 @@ JJS_HD void msig_commit_item(const msig_params& P, uint64_t i, uint32_t* ws) {
     store_ext(P.e_pt + EXT_WORDS * i, ext_add_niels(as, to_niels(r), false, true));
 }
 // pass 4 (lane per transcript): RSa = sum E_i, c = H(RSa, pk_agg, m), u = sum z_i
-JJS_HD void msig_final_item(const msig_params& P, uint32_t t) {
+JJS_HD void msig_final_item(const msig_params& P, uint32_t t, int coop = -1) {
     const uint32_t lo = P.offsets[t], hi = P.offsets[t + 1];
     const affine_words rsa = sum_points_affine(P.e_pt, lo, hi);
     store_point(P.sig_R, t, rsa);
     const fe_src sr{P.sig_R, 64, 0}, aggs{P.agg_pk, 64, 0}, ms{P.m, 32, 0}, zs{P.z, 32, 0};
     fe_n dg = poseidon_digest(5, [&](int e) {
         return e < 2 ? load_fq(sr, t, 32u * (uint32_t)e) : (e < 4 ? load_fq(aggs, t, 32u * (uint32_t)(e - 2)) : load_fq(ms, t));
-    });
+    }, coop);
     store_w8(P.c_words + 8 * t, truncate250(dg));
     // u = sum z_i mod r
     words8 u = small_words(0);

@@ -34,6 +34,21 @@ def test_field_ops_match_bigint():
         assert to_int(inv[i]) == (pow(x, o.Q - 2, o.Q) if x else 0)
 
 
+def test_fq_inverse_by_division_steps():
+    """csrc/fq_inv.h (safegcd division steps, 20 batches of 30) against a^(q-2): the values at which such code breaks -- 0, 1, 2,
+    q - 1, q - 2, (q + 1) / 2, powers of two around the limb boundaries of both radices, all-ones patterns -- and 3 000 random ones."""
+    rng = np.random.default_rng(77)
+    vals = [0, 1, 2, 3, o.Q - 1, o.Q - 2, (o.Q + 1) // 2, (o.Q - 1) // 2, 2**254, 2**254 + 1, 2**255 - 19 - o.Q if 2**255 - 19 > o.Q else 5]
+    vals += [2**k for k in (29, 30, 31, 32, 58, 59, 60, 64, 87, 90, 120, 232, 240, 253)] + [2**k - 1 for k in (29, 30, 60, 90, 240, 254)]
+    vals += [o.Q - 2**k for k in (1, 29, 30, 60, 200)] + [pow(3, k, o.Q) for k in (100, 1000, 10**6)]
+    vals = [v % o.Q for v in vals]
+    a = np.concatenate([np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8) for v in vals]), rand_mod(rng, 3000, o.Q)])
+    inv = hl.fq_inv(a)
+    for i in range(len(a)):
+        x = to_int(a[i])
+        assert to_int(inv[i]) == (pow(x, o.Q - 2, o.Q) if x else 0), hex(x)
+
+
 def test_poseidon_matches_oracle():
     rng = np.random.default_rng(4)
     for k in (1, 4, 5, 7, 8, 10, 15):
