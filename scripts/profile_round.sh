@@ -3,7 +3,10 @@
 # MI355X_MICROARCH.md prescribes), benches, phase profile with the gather ablation, clock / power sample.
 # Usage (through gpurun): bash scripts/profile_round.sh <tag> [schemes]  -> files under gpurun_out/, summaries in
 # profiles/<tag>_pmc_summary*.json and profiles/pmc_latest.json (stamped with the csrc hash)
+# PART=1: the counter passes and benches only; PART=2: the small-call records, the timeline and the clock sample only (a pass
+# is longer than one gpurun call allows; part 2 needs part 1's files under gpurun_out/ only for the last two lines of output)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r04}; SCHEMES=${2:-"single double vargen"}; cd /tmp && export TMPDIR=/tmp
+if [ "${PART:-0}" != 2 ]; then
 for S in $SCHEMES single_unique; do
   KEYS=""; U=0; SS=$S
   if [ "$S" = "single_unique" ]; then SS=single; KEYS="--keys 1048576"; U=1; fi
@@ -28,7 +31,10 @@ for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/to
 for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/tools/batch_size_curve.py $s > gpurun_out/batch_size_curve_${T}_$s.jsonl 2>/dev/null; done
 timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_${T}.jsonl 2>/dev/null
 for s in single double vargen; do timeout -k 10 200 python -m jubjub_schnorr_amd.tools.tail_bound $s 3 >> gpurun_out/tail_bound_${T}.jsonl 2>/dev/null; done
+fi   # PART != 2
+if [ "${PART:-0}" != 1 ]; then
 bash scripts/r04_small_calls.sh ${T} full
 bash scripts/timeline.sh ${T} single
 bash scripts/clock_sample.sh $T
+fi
 cut -c1-200 gpurun_out/bench_${T}.json; tail -3 gpurun_out/pmc_${T}_single.log

@@ -8,6 +8,10 @@ T=${1:-r04}
 if [ "$2" = full ]; then
   timeout -k 10 500 python -m jubjub_schnorr_amd.tools.small_host_calls --schemes single,double,vargen --threads 1 > gpurun_out/${T}_small_host_calls.jsonl 2> gpurun_out/${T}_small_host_calls.err || exit 1
   timeout -k 10 500 python -m jubjub_schnorr_amd.tools.small_host_calls --schemes single,double,vargen --c-client >> gpurun_out/${T}_small_host_calls.jsonl 2>> gpurun_out/${T}_small_host_calls.err || exit 1
+  # the reference's own API from a busy service: one signature (and 64) per call, up to 64 threads
+  for n in 1 64; do
+    timeout -k 10 300 python -m jubjub_schnorr_amd.tools.small_host_calls --schemes single --formats affine --sizes 1 --threads 1,2,4,8,16,32,64 --items-per-call $n --c-client 2>> gpurun_out/${T}_small_host_calls.err | grep threads >> gpurun_out/${T}_small_host_calls.jsonl || exit 1
+  done
 else
   timeout -k 10 300 python -m jubjub_schnorr_amd.tools.small_host_calls --schemes single --formats affine --sizes 1,1024,4096 --c-client > gpurun_out/${T}_small_host_calls.jsonl 2> gpurun_out/${T}_small_host_calls.err || exit 1
 fi
