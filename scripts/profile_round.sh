@@ -32,6 +32,7 @@ for s in single double vargen; do timeout -k 10 200 python jubjub_schnorr_amd/to
 timeout -k 10 200 python jubjub_schnorr_amd/tools/concurrent_calls.py > gpurun_out/concurrent_calls_${T}.jsonl 2>/dev/null
 for s in single double vargen; do timeout -k 10 200 python -m jubjub_schnorr_amd.tools.tail_bound $s 3 >> gpurun_out/tail_bound_${T}.jsonl 2>/dev/null; done
 fi   # PART != 2
+cd $R
 if [ "${PART:-0}" != 1 ]; then
 bash scripts/r04_small_calls.sh ${T} full
 bash scripts/timeline.sh ${T} single
