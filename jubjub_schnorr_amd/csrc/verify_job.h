@@ -371,7 +371,8 @@ int job_ingest(verify_job& J, uint64_t first, uint64_t count, uint32_t cols, hip
     if (!count) return JJS_OK;
     if (J.C.ext)
         if (int rc = launch_normalize(J.C.N[cols & 3u], first, count, J.C.P.n, cs)) return rc;
-    if (J.C.wire && (cols & COLS_REST)) {              // R (R') of every item
+    if (J.C.wire && (cols & COLS_REST) && !J.small) {  // R (R') of every item (the latency path decodes every point of the call
+                                                       // in ONE launch, a lane each: job_hash)
         decode_params D = J.C.W.sig;
         D.first = first; D.n = count;
         D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
@@ -457,8 +458,18 @@ int job_hash(verify_job& J, uint64_t first, uint64_t count, hipStream_t cs) {
     const verify_params& P = J.C.P;
     if (J.small) {
         if (first != 0 || count != P.n) return fail(JJS_ERR_ARG, "internal: the latency path takes the call whole");
-        if (J.C.wire)
-            if (int rc = launch_key_decode_per_item(J, 0, P.n, nullptr, cs)) return rc;
+        if (J.C.wire) {
+            // every compressed point of the call -- the R points of the signatures and the key columns -- in one launch, one lane
+            // per point: the call waits for ONE square root (0.17 ms) instead of one per point of an item, one after the other
+            // (single 0.33 ms, double 0.70: profiles/r04_wire_small_ab.jsonl)
+            const wire_keys& W = J.C.W;
+            decode_params D = W.sig;
+            for (uint32_t c = 0; c < W.n_cols && D.n_src < 4; ++c) { D.src[D.n_src] = W.comp[c]; D.out[D.n_src] = W.out[c]; ++D.n_src; }
+            D.first = 0; D.n = P.n; D.bad = W.bad; D.ok = nullptr; D.split = 1; D.skip_flag = nullptr;
+            D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
+            hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n * D.n_src)), dim3(BLOCK), 0, cs, D);
+            HIP_TRY(hipGetLastError());
+        }
         return launch_small(P, cs);
     }
     if (J.C.wire) {
