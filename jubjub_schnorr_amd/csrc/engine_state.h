@@ -133,6 +133,8 @@ constexpr int N_SLOTS = 1 + N_SMALL_SLOTS + N_MEDIUM_SLOTS + (N_BIG_SLOTS - 1);
 constexpr size_t SMALL_PATH_MAX_ITEMS[3] = {0, 16384, 16384};
 // up to here the scalars are cut into 8 pieces instead of 4 (small_batch.h): shorter tail, twice the chain work
 constexpr size_t SMALL_PATH_FINE_ITEMS[3] = {0, 4096, 4096};
+// up to here eight lanes share the challenge hash of a fixed-generator signature (launch_small)
+constexpr size_t SMALL_PATH_COOP_ITEMS = 6144;
 // the per-item-generator scheme (full-size scalars on two variable points: the chains are twice as long)
 constexpr size_t SMALL_PATH_MAX_ITEMS_VARGEN = 16384, SMALL_PATH_FINE_ITEMS_VARGEN = 4096;
 
@@ -500,7 +502,10 @@ int launch_small(verify_params P, hipStream_t s) {
     S.quad_chains = (small_fine_cut(P, others) && (vargen ? P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS : (P.n_eq == 1 && P.n <= SMALL_QUAD_CHAIN_MAX_ITEMS_FIXED))) ? 1u : 0u;
     // eight lanes per hash where the hash is the critical path -- a fixed generator, or a per-item generator whose chains run on
     // quads -- and the batch leaves lanes idle
-    S.hash_lanes = (small_fine_cut(P, others) && (!vargen || S.quad_chains)) ? SB_HASH_LANES : 1;
+    // (a fixed generator: up to SMALL_PATH_COOP_ITEMS, beyond the fine cut -- 6 144 single signatures 0.58 against 0.70 ms, double
+    // 0.78 against 0.93; at 8 192 the eightfold hash lanes no longer fit beside the chains: 0.76 against 0.71,
+    // profiles/r04_small_call_chain.jsonl)
+    S.hash_lanes = ((small_fine_cut(P, others) && (!vargen || S.quad_chains)) || (!vargen && others < SMALL_ECONOMY_FROM && P.n <= SMALL_PATH_COOP_ITEMS)) ? SB_HASH_LANES : 1;
     const unsigned hash_blocks = (unsigned)((P.n * S.hash_lanes + BLOCK - 1) / BLOCK);
     const unsigned chain_blocks = (unsigned)((P.n * P.n_eq * 2 * (S.quad_chains ? 4 : 1) + BLOCK - 1) / BLOCK);
     const unsigned point_blocks = (unsigned)((P.n * P.n_points + BLOCK - 1) / BLOCK);

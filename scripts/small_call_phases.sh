@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r04}; N=${2:-64}; SCHEMES=${3:-single double vargen}; LIB=${4:-}; SKIPS=${5:-0 2}; [ -n "$LIB" ] && LIB=$R/$LIB; cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/${T}_small_call_phases.jsonl
 for s in $SCHEMES; do for skip in $SKIPS; do
-  D=$R/gpurun_out/small_phases_${s}_$skip
+  D=$R/gpurun_out/small_phases_${T}_${s}_$skip; rm -rf $D
   timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/scripts/small_call_trace.py $s $N $skip $LIB > $D.log 2>&1 || exit 1
   python3 - "$(find $D -name '*kernel_trace.csv' | head -1)" $s $N $skip "$LIB" >> $OUT <<'PY'
 import csv, json, statistics, sys

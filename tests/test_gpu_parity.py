@@ -738,11 +738,11 @@ def test_both_paths_at_every_size():
 
 @pytest.mark.parametrize("scheme,limit", [("single", 16384), ("double", 16384), ("vargen", 16384), ("single", 4096), ("double", 4096),
                                           ("vargen", 4096), ("single", 512), ("double", 1024), ("vargen", 256), ("single", 1024),
-                                          ("vargen", 2048)])
+                                          ("vargen", 2048), ("single", 6144), ("double", 6144)])
 def test_path_boundary(eng, scheme, limit):
     """Either side of the sizes at which the product changes method (csrc/engine_state.h SMALL_PATH_FINEST_ITEMS: 16 -> 8
     pieces on the latency path; SMALL_QUAD_CHAIN_MAX_ITEMS*: chains on quads -> on single lanes; SMALL_PATH_FINE_ITEMS: 8 -> 4
-    pieces; SMALL_PATH_MAX_ITEMS: latency -> throughput path), against the oracle."""
+    pieces; SMALL_PATH_COOP_ITEMS: eight hash lanes -> one; SMALL_PATH_MAX_ITEMS: latency -> throughput path), against the oracle."""
     b = make_batch(scheme, limit + 1, seed=4711, n_keys=64)
     want = oracle_verify(scheme, b)
     for n in (limit, limit + 1):
