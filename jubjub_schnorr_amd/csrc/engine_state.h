@@ -164,7 +164,8 @@ struct host_lane {
     bool combinable = false;          // further calls may join while it is OPEN
     bool combinable_shape = false;    // a launch of combinable calls (LAUNCHED: no second one of its shape beside it)
     size_t cap = 0, items = 0;        // items the layout holds / items the members have claimed
-    unsigned copying = 0, members = 0;
+    unsigned copying = 0;             // members still copying their rows in (under the engine's mutex)
+    std::atomic<unsigned> members{0}; // written under the mutex; the leader reads it while it holds the window open
     std::chrono::steady_clock::time_point gather_until{};    // not launched before (see COMBINE_WINDOW_US) ...
 #if defined(JJS_LANE_TRACE)
     std::chrono::steady_clock::time_point trace_open{}, trace_done{};

@@ -230,7 +230,7 @@ static int lane_call(int scheme, int format, const uint8_t* const* cols, size_t 
                 // callers that are on their way may still join (a short spin: the timers of a sleeping wait are coarser than this)
                 const unsigned expect = lane->expect;
                 lock.unlock();
-                while (__atomic_load_n(&lane->members, __ATOMIC_RELAXED) < expect && std::chrono::steady_clock::now() < until) cpu_relax();
+                while (lane->members.load(std::memory_order_relaxed) < expect && std::chrono::steady_clock::now() < until) cpu_relax();
                 lock.lock();
                 if (lane->members < expect) lane->expect = 0;          // the window has passed: whoever has joined, joined
                 continue;
