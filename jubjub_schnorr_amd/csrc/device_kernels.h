@@ -419,8 +419,8 @@ __global__ __launch_bounds__(BLOCK) void challenge_kernel(challenge_params P) {
 
 struct decode_params {
     uint32_t n_src;
-    uint32_t split;       // 1: one lane per (item, source) instead of one per item -- the calls of the latency path, which wait
-                          // for the one square root of a point (~330 dependent products), not for how many there are
+    uint32_t split;       // 1 (decode_points_kernel): one lane per (item, source) instead of one per item -- the calls of the latency
+                          // path, which wait for the one square root of a point (~330 dependent products), not for how many there are
     fe_src src[4];        // compressed points: 32 bytes at base + i*stride + off
     uint8_t* out[4];      // affine u || v, n x 64 each
     uint8_t* bad;         // n bytes, set to 1 when any source of item i fails to decode (nullable)
@@ -437,27 +437,6 @@ __global__ __launch_bounds__(BLOCK) void dlog_table_kernel(uint32_t* pow, uint8_
 __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
     if (P.skip_flag && *P.skip_flag) return;
     const uint64_t total = (uint64_t)gridDim.x * BLOCK;
-    if (P.split) {
-        for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < P.n * P.n_src; j += total) {
-            const uint64_t item = P.first + j / P.n_src;
-            const uint32_t k = (uint32_t)(j % P.n_src);
-            // source and destination chosen field by field: indexing the kernel-argument struct with a run-time index would
-            // make the compiler copy it to scratch memory
-            fe_src src = P.src[0];
-            uint8_t* out = P.out[0];
-#pragma unroll
-            for (uint32_t c = 1; c < 4; ++c) {
-                const bool me = k == c;
-                src.base = me ? P.src[c].base : src.base; src.stride = me ? P.src[c].stride : src.stride; src.off = me ? P.src[c].off : src.off;
-                out = me ? P.out[c] : out;
-            }
-            const decoded_point d = decompress_point(load_words(src, item), P.dlog);
-            store_words(out, 2 * item, d.u);
-            store_words(out, 2 * item + 1, d.v);
-            if (P.bad && !d.ok) P.bad[item] = 1;          // several lanes of an item may write the same 1
-        }
-        return;
-    }
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += total) {
         const uint64_t item = P.first + i;
         bool all_ok = true;
@@ -469,6 +448,29 @@ __global__ __launch_bounds__(BLOCK) void decode_kernel(decode_params P) {
         }
         if (P.bad && !all_ok) P.bad[item] = 1;
         if (P.ok) P.ok[item] = all_ok ? 1 : 0;
+    }
+}
+// The same, one lane per (item, source): the calls of the latency path (decode_params::split).  A kernel of its own: as a branch
+// of decode_kernel it cost the resident 2^20 wire batch 4.8 % (profiles/r04_wire_small_ab.jsonl).
+__global__ __launch_bounds__(BLOCK) void decode_points_kernel(decode_params P) {
+    const uint64_t total = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < P.n * P.n_src; j += total) {
+        const uint64_t item = P.first + j / P.n_src;
+        const uint32_t k = (uint32_t)(j % P.n_src);
+        // source and destination chosen field by field: indexing the kernel-argument struct with a run-time index would
+        // make the compiler copy it to scratch memory
+        fe_src src = P.src[0];
+        uint8_t* out = P.out[0];
+#pragma unroll
+        for (uint32_t c = 1; c < 4; ++c) {
+            const bool me = k == c;
+            src.base = me ? P.src[c].base : src.base; src.stride = me ? P.src[c].stride : src.stride; src.off = me ? P.src[c].off : src.off;
+            out = me ? P.out[c] : out;
+        }
+        const decoded_point d = decompress_point(load_words(src, item), P.dlog);
+        store_words(out, 2 * item, d.u);
+        store_words(out, 2 * item + 1, d.v);
+        if (P.bad && !d.ok) P.bad[item] = 1;          // several lanes of an item may write the same 1
     }
 }
 // Wire calls on the key-table path: one decompression per distinct key, then every item copies its key's point

@@ -467,7 +467,7 @@ int job_hash(verify_job& J, uint64_t first, uint64_t count, hipStream_t cs) {
             for (uint32_t c = 0; c < W.n_cols && D.n_src < 4; ++c) { D.src[D.n_src] = W.comp[c]; D.out[D.n_src] = W.out[c]; ++D.n_src; }
             D.first = 0; D.n = P.n; D.bad = W.bad; D.ok = nullptr; D.split = 1; D.skip_flag = nullptr;
             D.dlog = dlog_tables{g->dlog_pow, g->dlog_hash};
-            hipLaunchKernelGGL(decode_kernel, dim3((unsigned)grid_for(8192, P.n * D.n_src)), dim3(BLOCK), 0, cs, D);
+            hipLaunchKernelGGL(decode_points_kernel, dim3((unsigned)grid_for(8192, P.n * D.n_src)), dim3(BLOCK), 0, cs, D);
             HIP_TRY(hipGetLastError());
         }
         return launch_small(P, cs);
