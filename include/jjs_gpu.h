@@ -46,16 +46,18 @@
  * its launches are queued.  Host-buffer calls of at most 16 384 items run on staging lanes (eight per device), side by side
  * on the device; those of at most 4 096 items of one scheme and input format that arrive while another is running share
  * one launch (JJS_PATH_LANE_LAUNCHES / JJS_PATH_LANE_CALLS count them): four threads of 1 024-signature calls complete
- * about three times the calls per second of one thread, eight threads four to five times.  Larger host-buffer calls are pipelines of
+ * about three times the calls per second of one thread, eight threads four times; 64 threads of ONE-signature calls about thirty
+ * times (the callers of a shared launch other than the one that drives it sleep, so a service may have many more threads than
+ * cores).  Larger host-buffer calls are pipelines of
  * uploads and launches that fill the device: they run one at a time per device (other threads' calls are queued meanwhile;
- * with several driven devices such a call holds the mutex for its duration).  A call takes one of the engine's call slots by size (three for calls of
+ * with several driven devices such a call holds the mutex for its duration).  A call takes one of the engine's call slots by size (six for calls of
  * at most 16 384 items, three for at most 131 072, two for larger ones): calls in different slots share no buffer and
  * overlap on the device when they are issued on different streams; calls in one slot are ordered on the device (each
  * waits for the previous one, also across streams).
  *
  * Method: the engine picks, per call, from the batch size and the repetition of its keys alone (no configuration):
- * at most 16 384 items -> latency path (a signature spread over many lanes; ~0.55 ms single, ~0.75 ms double,
- * ~0.85 ms var-generator up to 4 096 items); larger -> one signature per lane; at least 65 536 items (32 768 for double
+ * at most 16 384 items -> latency path (a signature spread over many lanes: 0.37 ms single, 0.50 ms double, 0.41-0.47 ms
+ * var-generator for a call of a few hundred items, 0.55 / 0.71 / 0.85 ms at 4 096); larger -> one signature per lane; at least 65 536 items (32 768 for double
  * and var-generator signatures) whose public keys (and per-item generators) repeat 16 times or more on average ->
  * per-key tables built inside the call.  The
  * status bytes are the same on every path.
@@ -225,8 +227,9 @@ int jjs_verify_vargen_ext(const uint8_t* u, const uint8_t* R_ext, const uint8_t*
  * participants gets transcript_status 5, the reference's InvalidMultisigTranscript, and does not affect the others.
  * (The two sponge tags of a transcript of more than 256 participants are computed on the device inside the call.  The hashes
  * of a transcript are sponge chains -- (2 + 2n) / 4 permutations for each of the n delinearisation hashes, which run side by
- * side, one lane each, and (3 + 4n) / 4 for the binding hash, which is ONE chain -- so the time of a call grows linearly with
- * its longest transcript: about 0.3 ms per participant, 1 000 participants about 0.3 s.)
+ * side, and (3 + 4n) / 4 for the binding hash, which is ONE chain -- so the time of a call grows linearly with its longest
+ * transcript: about 0.2 ms per participant, 1 000 participants 0.21-0.24 s; a call with few items runs these chains on eight
+ * lanes each.)
  * Outputs (device): share_status[i] = 0 when z_i*G + (c*d_i)*PK_i == R_i + a*S_i, 4 (InvalidMultisigShare)
  * when not, 3 for a non-canonical encoding (z_i, a coordinate, or the transcript's m); transcript_status[t]
  * (B bytes, nullable) = 0 when `combine` returns a signature, else the status of the transcript's first failing
