@@ -150,12 +150,17 @@ int init_device(device_state& d, int ordinal) {
     // creation order, and the key streams of the big slots must have one each (scripts/timeline.sh: created behind two
     // other priority streams, the small launches of the first big slot's key stream waited 0.3-0.5 ms each for wave slots
     // instead of 0.1, and a resident 2^20 batch took 0.5 ms longer).
+    // The two streams on which a host-buffer call normalises extended points come right behind the big slots' key streams: a
+    // large host call runs in the second big slot, and with its ingest stream on the hardware queue of that slot's key stream the
+    // normalisation of its last range waited 1.6 ms behind the key chains and tables (scripts/host_timeline.sh ... ext; a 2^20-item
+    // single call 12.1-12.3 -> 11.6-11.8 ms, profiles/r04_host_ext_ab.jsonl).
     {
-        const int order[] = {0, SECOND_BIG_SLOT, 1 + N_SMALL_SLOTS, 2 + N_SMALL_SLOTS, 3 + N_SMALL_SLOTS};
         static_assert(N_MEDIUM_SLOTS == 3 && N_BIG_SLOTS == 2, "one entry per slot that has a key stream");
-        for (int i : order) HIP_TRY(hipStreamCreateWithPriority(&d.slots[i].key_stream, hipStreamNonBlocking, d.key_priority));
+        for (int i : {0, SECOND_BIG_SLOT}) HIP_TRY(hipStreamCreateWithPriority(&d.slots[i].key_stream, hipStreamNonBlocking, d.key_priority));
+        for (hipStream_t& is : d.ingest) HIP_TRY(hipStreamCreateWithPriority(&is, hipStreamNonBlocking, d.key_priority));
+        for (int i : {1 + N_SMALL_SLOTS, 2 + N_SMALL_SLOTS, 3 + N_SMALL_SLOTS})
+            HIP_TRY(hipStreamCreateWithPriority(&d.slots[i].key_stream, hipStreamNonBlocking, d.key_priority));
     }
-    for (hipStream_t& is : d.ingest) HIP_TRY(hipStreamCreateWithPriority(&is, hipStreamNonBlocking, d.key_priority));
     for (call_slot& c : d.slots)
         if (c.key_stream) HIP_TRY(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, d.table_priority));
     HIP_TRY(hipMalloc(&d.comb_g, COMB_TABLE_WORDS * sizeof(uint32_t)));

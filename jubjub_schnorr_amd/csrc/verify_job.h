@@ -281,7 +281,9 @@ int launch_normalize(normalize_params N, uint64_t first, uint64_t count, uint64_
         // measured 1-3 % SLOWER, 16 items per lane instead of 8 the same within noise: profiles/r04_ext_pipeline_ab*.txt)
         if (blocks > 512) blocks = 512;
     } else {
-        // a range of a host-buffer call: ~8 items per lane from 2^18 items on (an inversion is 12 items' worth of products)
+        // a range of a host-buffer call: ~8 items per lane from 2^18 items on (1, 2 or 4 items per lane, and the normalisation
+        // done by the hashing lanes themselves instead of a launch in front of them, are the same to a 2^20-item call within
+        // noise: such a call is bound by its uploads and by the key kernels behind the last key column, profiles/r04_host_ext_ab.jsonl)
         const size_t few = blocks < 64 ? blocks : 64, shared = (count + (size_t)BLOCK * 8 - 1) / ((size_t)BLOCK * 8);
         blocks = few > shared ? few : shared;
         if (blocks > 512) blocks = 512;
@@ -402,6 +404,7 @@ int job_keys(verify_job& J) {
 #if defined(JJS_AB_CHAIN_ONE_LANE)        // build-time knob of the A/B run recorded in DESIGN.md 6
     K.quad_chains = 0;
 #else
+    // (nor does a host-fed 2^20 call gain from them, although its key kernels end with its hashes: profiles/r04_host_ext_ab.jsonl)
     K.quad_chains = (P.n <= KEYS_AHEAD_MAX_ITEMS || K.n_cols >= 2) ? 1u : 0u;
 #endif
     J.Kd = K;                                   // a wire call deduplicates the 32-byte encodings
