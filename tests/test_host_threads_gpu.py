@@ -299,3 +299,33 @@ def test_sixty_four_threads_of_one_item_calls(eng, tmp_path):
     print(f"one-item calls/s (C client): 1 thread {one['calls_per_s']:.0f}, 64 threads {many['calls_per_s']:.0f} "
           f"({many['calls_per_s'] / one['calls_per_s']:.1f} x), {many['lane_calls'] / max(1, many['lane_launches']):.1f} calls per launch")
     assert many["calls_per_s"] >= 12 * one["calls_per_s"], (one, many)
+
+
+@pytest.mark.parametrize("n", [0, 1, 100, 5000, 20000])
+def test_host_calls_with_optional_outputs(eng, n):
+    """The blocking entry points with the outputs a caller may leave out (include/jjs_gpu.h: status and tally are nullable), an
+    empty batch, and a null input column: through the lanes (n <= 16 384) and through the pipeline (beyond)."""
+    import ctypes
+    from jubjub_schnorr_amd import _ffi
+    lib = _ffi.lib()
+    b = make_batch("single", max(n, 1), seed=6100 + n, n_keys=8)
+    want = oracle_verify("single", b)[:n]
+    cols = [np.ascontiguousarray(b[k][:n]) for k in ARG_ORDER["single"]]
+    ptrs = [c.ctypes.data_as(ctypes.c_void_p) for c in cols]
+    st = np.full(n, 0xEE, np.uint8)
+    tally = np.full(4, 77, np.uint64)
+    p_st, p_tally = st.ctypes.data_as(ctypes.c_void_p), tally.ctypes.data_as(ctypes.c_void_p)
+    assert lib.jjs_verify_single(*ptrs, n, p_st, p_tally) == 0
+    assert (st == want).all() and tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    st[:] = 0xEE
+    assert lib.jjs_verify_single(*ptrs, n, p_st, None) == 0              # statuses only
+    assert (st == want).all()
+    tally[:] = 77
+    assert lib.jjs_verify_single(*ptrs, n, None, p_tally) == 0           # tally only
+    assert tally.tolist() == [int((want == k).sum()) for k in range(4)]
+    assert lib.jjs_verify_single(*ptrs, n, None, None) == 0              # nothing asked for: still a valid call
+    if n:
+        bad = list(ptrs)
+        bad[2] = None
+        assert lib.jjs_verify_single(*bad, n, p_st, p_tally) != 0        # a missing column is refused
+        assert b"null" in lib.jjs_last_error()
