@@ -28,10 +28,10 @@ constexpr int N = 512;
 constexpr int OUT_WORDS = 64;   // per item per stage
 
 enum Stage { S_MUL, S_SQR, S_ADDSUB, S_REDUCE, S_DOT5, S_SBOX, S_ROUND_FULL, S_ROUND_PARTIAL, S_PERMUTE, S_DOUBLE, S_ADD,
-             S_ONCURVE, S_TORSION, S_CANON, S_EUCLID, N_STAGES };
+             S_ONCURVE, S_TORSION, S_CANON, S_EUCLID, S_INVERSE, N_STAGES };
 static const char* kStageNames[] = {"mul", "sqr", "add/sub/norm", "reduce", "dot5", "sbox", "hades round (full)",
                                     "hades round (partial)", "hades permute", "ext_double", "ext_add_niels", "on_curve",
-                                    "torsion", "canon/to_words", "half-size scalars (Euclid)"};
+                                    "torsion", "canon/to_words", "half-size scalars (Euclid)", "inverse (division steps / power)"};
 
 __host__ __device__ inline void put(uint32_t* out, int& pos, const uint32_t* l, int n) { for (int i = 0; i < n; ++i) out[pos++] = l[i]; }
 
@@ -100,6 +100,14 @@ __host__ __device__ inline void run_stage(int stage, const uint32_t* in, uint32_
         half_scalars h = half_size_scalars(cw);
         put(out, pos, h.a.w, 4); put(out, pos, h.b.w, 4); out[pos++] = h.b_neg ? 1u : 0u;
         break; }
+    case S_INVERSE: {
+        // csrc/fq_inv.h against the power it replaced, on the device as on the host; and a * (1/a) == 1
+        const words8 r = fq_to_words(fq_inverse(a)), p = fq_to_words(fq_inverse_by_power(a)), one = fq_to_words(fq_mul(a, fq_inverse(a)));
+        put(out, pos, r.w, 8); put(out, pos, p.w, 8); put(out, pos, one.w, 8);
+        uint32_t diff = 0;
+        for (int i = 0; i < 8; ++i) diff |= r.w[i] ^ p.w[i];
+        out[pos++] = diff ? 0xBADu : 0u;
+        break; }
     }
 }
 
@@ -150,7 +158,8 @@ int main() {
         CHECK(hipMemcpy(dev_out.data(), dout, dev_out.size() * 4, hipMemcpyDeviceToHost));
         int mism = 0, first = -1;
         for (int i = 0; i < n_host; ++i)
-            if (memcmp(&host_out[OUT_WORDS * i], &dev_out[OUT_WORDS * i], OUT_WORDS * 4)) { if (first < 0) first = i; ++mism; }
+            if (memcmp(&host_out[OUT_WORDS * i], &dev_out[OUT_WORDS * i], OUT_WORDS * 4) ||
+                (st == S_INVERSE && dev_out[OUT_WORDS * i + 24] != 0)) { if (first < 0) first = i; ++mism; }      // [24]: the two inversions differ
         printf("stage %-24s items %4d mismatches %4d%s\n", kStageNames[st], n_host, mism, mism ? "  <-- DIFFERS" : "");
         if (mism) {
             ++bad_stages;

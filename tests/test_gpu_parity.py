@@ -816,3 +816,16 @@ def test_calls_on_different_streams_do_not_interfere(eng):
         want = oracle_verify(s, b)
         assert host(st).tolist() == want.tolist()
         assert host(tally).tolist() == [int((want == k).sum()) for k in range(4)]
+
+
+def test_devcheck_device_against_host_stage_by_stage():
+    """tools/devcheck: the same csrc/*.h functions on the device and on the host (field products, Hades rounds, point
+    formulas, the pairing test, the Lehmer Euclid, the inversion by division steps against the power), raw limbs compared
+    stage by stage -- what localises a miscompile or a device-only arithmetic difference."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jubjub_schnorr_amd", "tools", "devcheck")
+    if not os.path.exists(exe):
+        pytest.skip("tools/devcheck not built (python -c 'import __graft_entry__ as g; g.build()')")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "DEVCHECK OK" in p.stdout, p.stdout[-3000:] + p.stderr[-1000:]
+    assert "inverse" in p.stdout
